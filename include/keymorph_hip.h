@@ -64,6 +64,15 @@ int kmh_argmax_onehot(const float* pred, int N, int C, long long V, float* out, 
 int kmh_jacobian_det(const float* disp, long long cstride, long long vstride, int D, int H, int W, float* jd,
                      double* stats, void* ws, void* stream);
 
+/* ---- label-map encodings in front of the Dice branch: keymorph/utils.py:200-240 (one_hot,
+ * one_hot_subsampled_pair; callers scripts/train.py:54-61) ---- */
+/* flags: nflags + 1 ints zeroed by the caller; flags[l] = 1 iff label l occurs among the n int64 values of seg,
+ * flags[nflags] = 1 iff a label lies outside [0, nflags) (replaces np.unique on the host). */
+int kmh_label_presence(const long long* seg, long long n, int nflags, int* flags, void* stream);
+/* out[n,c,v] = (seg[n,v] == labels[c]), C <= 256; float32 out (out_i64 = 0) or int64 out like F.one_hot (1). */
+int kmh_one_hot_select(const long long* seg, int N, long long V, const long long* labels, int C, void* out,
+                       int out_i64, void* stream);
+
 /* ---- a9: AffineTransform.get_flow_field, keymorph/transformations.py:37-79 and
  *      uniform_norm_grid keymorph/utils.py:387-398.  mat (N,3,4) = inverse_transform_matrix[:, :3, :]
  *      acting on ij coords; out (N,D,H,W,3) already flipped to xyz. */

@@ -48,6 +48,8 @@ PROTOS = {
     "kmh_affine_inverse_bwd": (_i, [_f, _f, _f, _i, _f]),
     "kmh_affine_points_fwd": (_i, [_f, _f, _f, _i, _i, _f]),
     "kmh_jacobian_det": (_i, [_f, _ll, _ll, _i, _i, _i, _f, _f, _f, _f]),
+    "kmh_label_presence": (_i, [_f, _ll, _i, _f, _f]),
+    "kmh_one_hot_select": (_i, [_f, _i, _ll, _f, _i, _f, _i, _f]),
     "kmh_affine_build_matrix": (_i, [_f, _f, _f, _f, _f, _i, _f]),
     "kmh_affine_points_bwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _f]),
     "kmh_com3d_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f]),

@@ -26,7 +26,9 @@ class AffineDeformation3d:
         """params = (scale (bs,3), offset (bs,3), theta (bs,3), shear (bs,6)) -> (bs,4,4);
         M = Mz Ms Mt Mr with Mr = R3 R2 R1 (augmentation.py:85-158)."""
         lib = _lib.load()
-        scale, offset, theta, shear = (p.to(self.device, torch.float32).contiguous() for p in params)
+        # (1, k) parameters broadcast over the batch like the reference's (1,)-shaped tensors do (augmentation.py:96-158)
+        scale, offset, theta, shear = (p.to(self.device, torch.float32).expand(batch_size, -1).contiguous()
+                                       for p in params)
         for p, k in ((scale, 3), (offset, 3), (theta, 3), (shear, 6)):
             assert tuple(p.shape) == (batch_size, k), f"expected ({batch_size}, {k}) parameters, got {tuple(p.shape)}"
         out = torch.empty((batch_size, 4, 4), dtype=torch.float32, device=self.device)
@@ -67,7 +69,7 @@ def _apply(augmenter, params, img, seg, points, matrix):
 
 def random_affine_augment(img, seg=None, points=None, max_random_params=(0.2, 0.2, 3.1416, 0.1), scale_params=1,
                           return_affine_matrix=False):
-    """augmentation.py:162-207.  img (bs, nch, D, H, W); bs must be 1 like the reference's (1, k) parameters."""
+    """augmentation.py:162-207.  img (bs, nch, D, H, W); the one (1, k) parameter draw is applied to every sample of the batch."""
     s, o, a, z = (p * scale_params for p in max_random_params)
     params = _draw(img, ((1 - s, 1 + s), (-o, o), (-a, a), (-z, z)))
     return _apply(AffineDeformation3d(device=img.device), params, img, seg, points, return_affine_matrix)

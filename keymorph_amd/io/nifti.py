@@ -63,8 +63,11 @@ def read_nifti(path, dtype=np.float32):
     if dtype is None:
         return np.ascontiguousarray(arr), A
     out = arr.astype(dtype)
-    if slope not in (0.0, 1.0) or inter != 0.0:
-        if slope != 0.0:
+    # NIfTI-1: scaling applies only for a finite, non-zero scl_slope; nibabel writes NaN into both fields for
+    # float images ("no scaling") and a non-finite scl_inter counts as 0.
+    if np.isfinite(slope) and slope != 0.0:
+        inter = inter if np.isfinite(inter) else 0.0
+        if slope != 1.0 or inter != 0.0:
             out = out * dtype(slope) + dtype(inter)
     return np.ascontiguousarray(out), A
 

@@ -51,6 +51,32 @@ class AffineKeypointAligner(AffineTransform):
             points = convert_points_real2norm(points, self.aff_m, self.shape_m)
         return points
 
+    def _norm_to_norm_inverse_matrix(self):
+        """Real-world mode: the map the sampling grid needs is fixed-norm -> fixed-mm -> moving-mm -> moving-norm
+        (keypoint_aligners.py:134-148 applied to every grid point by transformations.py:37-58).  All three stages
+        are affine, so they compose into ONE (1, 3, 4) matrix for the grid kernel:
+            norm2real_f = aff_f . [diag(S_f/2) | S_f/2 - 1/2]        (utils.py:243-259, 275-291)
+            real2norm_m = [diag(2/S_m) | 1/S_m - 1] . aff_m^-1       (utils.py:262-272, 294-317)
+        composed in fp64 (mm-scale entries; the product is back in [-1, 1] units), differentiable in the fit."""
+        dd = torch.float64
+        dev = self.inverse_transform_matrix.device
+        sf = torch.as_tensor(self.shape_f).to(dev, dd).reshape(-1)
+        sm = torch.as_tensor(self.shape_m).to(dev, dd).reshape(-1)
+        n2v = torch.eye(4, dtype=dd, device=dev)
+        n2v[:3, :3] = torch.diag(sf / 2)
+        n2v[:3, 3] = sf / 2 - 0.5
+        v2n = torch.eye(4, dtype=dd, device=dev)
+        v2n[:3, :3] = torch.diag(2 / sm)
+        v2n[:3, 3] = 1 / sm - 1
+        n2r_f = self.aff_f.to(dev, dd) @ n2v
+        r2n_m = v2n @ torch.inverse(self.aff_m.to(dev, dd))
+        return (r2n_m @ self.inverse_transform_matrix.to(dd) @ n2r_f).float()
+
+    def get_flow_field(self, grid_shape, **kwargs):
+        if not self.align_in_real_world_coords:
+            return super().get_flow_field(grid_shape, **kwargs)
+        return ops.affine_grid(self._norm_to_norm_inverse_matrix()[:, :3, :].contiguous(), grid_shape[2:])
+
     def grid_from_points(self, points_m, points_f, grid_shape, lmbda=None, weights=None, compute_on_subgrids=False):
         """README.md:74 compatibility shim: construct + get_flow_field."""
         return type(self)(points_m=points_m, points_f=points_f, w=weights, dim=self.dim).get_flow_field(grid_shape)

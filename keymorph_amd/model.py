@@ -158,6 +158,8 @@ class KeyMorph(nn.Module):
                 idx = np.random.choice(self.num_keypoints, size=self.max_train_keypoints, replace=False)
                 points_f = points_f[:, idx]
                 points_m = points_m[:, idx]
+                if weights is not None:      # model.py:221-222: the weights follow their keypoints
+                    weights = weights[:, idx]
             aligner = self._make_aligner(align_type, points_m, points_f, tps_lmbda, weights, aff)
             grid = aligner.get_flow_field(img_f.shape, compute_on_subgrids=not self.training)
             if return_aligned_points:

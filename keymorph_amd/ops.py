@@ -31,6 +31,12 @@ def _prep(t: Tensor, name: str = "tensor") -> Tensor:
     if not t.is_cuda:
         raise _lib.KeymorphHipError(
             f"{name} is on {t.device}: keymorph_amd ops run only on an AMD GPU (no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        # the C ABI launches on the CURRENT device's stream and never calls hipSetDevice: a tensor that lives on
+        # another GPU would be touched by kernels queued on the wrong device
+        raise _lib.KeymorphHipError(
+            f"{name} is on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+            "call torch.cuda.set_device(...) (one process per GPU) before using keymorph_amd ops")
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()

@@ -49,29 +49,63 @@ def rescale_intensity(array, out_range=(0, 1), percentiles=(0, 100)):
     return array
 
 
+_MAX_LABEL = 1 << 16     # label ids handled by the presence bitmap (FreeSurfer / BrainMorph label maps are < 2^16)
+
+
+def _seg_on_gpu(seg):
+    """The reference's loops call the encoders on the loader's CPU tensors and move the result to the device
+    afterwards (scripts/train.py:54-79); here the label map goes to the current GPU first and the encoding is
+    returned there (the later ``.float().to(device)`` is then a no-op)."""
+    if not seg.is_cuda:
+        seg = seg.to(torch.device("cuda", torch.cuda.current_device()))
+    if seg.dtype != torch.int64:
+        seg = seg.long()
+    return seg.contiguous()
+
+
+def _labels_present(seg):
+    """Sorted label ids occurring in an int64 label map on the GPU (np.unique of the reference, utils.py:210-211)."""
+    from . import _lib
+    lib = _lib.load()
+    flags = torch.zeros(_MAX_LABEL + 1, dtype=torch.int32, device=seg.device)
+    ops.check(lib.kmh_label_presence(ops._p(seg), seg.numel(), _MAX_LABEL, ops._p(flags), ops._stream()),
+              "kmh_label_presence")
+    flags = flags.cpu().numpy()
+    if flags[_MAX_LABEL]:
+        raise ValueError(f"label ids must lie in [0, {_MAX_LABEL}) (F.one_hot also rejects negative labels)")
+    return np.nonzero(flags[:_MAX_LABEL])[0].astype(np.int64)
+
+
+def _encode(seg, labels, as_int64):
+    from . import _lib
+    lib = _lib.load()
+    if len(labels) > 256:
+        raise ValueError("at most 256 one-hot channels")
+    n = seg.shape[0]
+    v = seg.numel() // n
+    lab = torch.as_tensor(np.asarray(labels, dtype=np.int64), device=seg.device)
+    out = torch.empty((n, len(labels), *seg.shape[2:]), dtype=torch.int64 if as_int64 else torch.float32,
+                      device=seg.device)
+    ops.check(lib.kmh_one_hot_select(ops._p(seg), n, v, ops._p(lab), len(labels), ops._p(out), int(as_int64),
+                                     ops._stream()), "kmh_one_hot_select")
+    return out
+
+
 def one_hot(seg):
-    """(N,1,D,H,W) integer labels -> (N,C,D,H,W): utils.py:200-205."""
-    return F.one_hot(seg)[:, 0].permute(0, 4, 1, 2, 3)
+    """(N,1,D,H,W) integer labels -> (N,C,D,H,W) int64, C = largest label + 1: utils.py:200-205."""
+    assert seg.shape[1] == 1, "expected a (N, 1, ...) label map"
+    seg = _seg_on_gpu(seg)
+    present = _labels_present(seg)
+    return _encode(seg, np.arange(int(present.max()) + 1), True)
 
 
 def one_hot_subsampled_pair(seg1, seg2, subsample_num=14):
-    """utils.py:208-240: one-hot over (a random subset of) the labels both maps share."""
-    u1 = np.unique(seg1.cpu().detach().numpy())
-    u2 = np.unique(seg2.cpu().detach().numpy())
-    shared = np.intersect1d(u1, u2, assume_unique=True)
-    if len(shared) > subsample_num:
-        chosen = np.random.choice(shared, subsample_num, replace=False)
-    else:
-        chosen = shared
-        subsample_num = len(shared)
-
-    def encode(seg):
-        out = torch.zeros((seg.shape[0], subsample_num, *seg.shape[2:]), dtype=torch.float32, device=seg.device)
-        for i, val in enumerate(chosen):
-            out[:, i] = (seg == val).float()[:, 0] if seg.shape[1] == 1 else (seg == val).float()
-        return out
-
-    return encode(seg1), encode(seg2)
+    """utils.py:208-240: float32 one-hot over (an np.random.choice subset of) the labels both maps contain; the
+    draw is the reference's (same generator, same arguments), so a seeded script selects the same channels."""
+    seg1, seg2 = _seg_on_gpu(seg1), _seg_on_gpu(seg2)
+    shared = np.intersect1d(_labels_present(seg1), _labels_present(seg2), assume_unique=True)
+    chosen = np.random.choice(shared, subsample_num, replace=False) if len(shared) > subsample_num else shared
+    return _encode(seg1, chosen, False), _encode(seg2, chosen, False)
 
 
 def _homog(points):

@@ -335,21 +335,25 @@ def _gn_groups(channels: int, num_groups: int) -> int:
     return 1 if channels < num_groups else num_groups
 
 
-def single_conv_gcr(sd: Dict[str, Tensor], prefix: str, x: Tensor, num_groups: int) -> Tensor:
-    """GroupNorm -> Conv3d(k3,p1,no bias) -> ReLU: keymorph/unet3d/buildingblocks.py:10-93."""
+def single_conv_gcr(sd: Dict[str, Tensor], prefix: str, x: Tensor, num_groups: int,
+                    taps: Optional[List[Tensor]] = None) -> Tensor:
+    """GroupNorm -> Conv3d(k3,p1,no bias) -> ReLU: keymorph/unet3d/buildingblocks.py:10-93.
+    ``taps``: if given, the pre-ReLU tensor is appended (tests use it to locate ReLU-kink voxels)."""
     g = _gn_groups(x.shape[1], num_groups)
     x = F.group_norm(x, g, sd[prefix + "groupnorm.weight"], sd[prefix + "groupnorm.bias"], 1e-5)
     x = F.conv3d(x, sd[prefix + "conv.weight"], None, padding=1)
+    if taps is not None:
+        taps.append(x.detach())
     return F.relu(x)
 
 
-def double_conv(sd, prefix, x, num_groups):
-    x = single_conv_gcr(sd, prefix + "SingleConv1.", x, num_groups)
-    return single_conv_gcr(sd, prefix + "SingleConv2.", x, num_groups)
+def double_conv(sd, prefix, x, num_groups, taps=None):
+    x = single_conv_gcr(sd, prefix + "SingleConv1.", x, num_groups, taps)
+    return single_conv_gcr(sd, prefix + "SingleConv2.", x, num_groups, taps)
 
 
 def unet3d_forward(sd: Dict[str, Tensor], x: Tensor, num_levels: int = 4,
-                   num_truncated: int = 0, num_groups: int = 8) -> Tensor:
+                   num_truncated: int = 0, num_groups: int = 8, taps: Optional[List[Tensor]] = None) -> Tensor:
     """UNet3D / TruncatedUNet3D forward ("gcr" DoubleConv, max-pool encoders,
     nearest-upsample + concat decoders, 1x1x1 final conv; logits returned):
     keymorph/unet3d/model.py:117-151, 307-391; buildingblocks.py:321-475,568-582."""
@@ -357,7 +361,7 @@ def unet3d_forward(sd: Dict[str, Tensor], x: Tensor, num_levels: int = 4,
     for i in range(num_levels):
         if i > 0:
             x = F.max_pool3d(x, 2)
-        x = double_conv(sd, f"encoders.{i}.basic_module.", x, num_groups)
+        x = double_conv(sd, f"encoders.{i}.basic_module.", x, num_groups, taps)
         feats.insert(0, x)
     feats = feats[1:]
     n_dec = num_levels - 1 - num_truncated
@@ -365,7 +369,7 @@ def unet3d_forward(sd: Dict[str, Tensor], x: Tensor, num_levels: int = 4,
         skip = feats[j]
         x = F.interpolate(x, size=skip.shape[2:], mode="nearest")
         x = torch.cat([skip, x], dim=1)
-        x = double_conv(sd, f"decoders.{j}.basic_module.", x, num_groups)
+        x = double_conv(sd, f"decoders.{j}.basic_module.", x, num_groups, taps)
     return F.conv3d(x, sd["final_conv.weight"], sd["final_conv.bias"])
 
 
@@ -433,6 +437,66 @@ def register(points_f: Tensor, points_m: Tensor, transform_type: str, shape: Seq
             th = tps_fit(points_m, points_f, lm, w)
             res["points_a"] = tps_transform_points(th, points_m, points_m)
     return res
+
+
+# --------------------------------------------------------------------------
+# a16  real-world-coordinate alignment (bs = 1)
+# --------------------------------------------------------------------------
+def norm2real(points: Tensor, affine: Tensor, sizes: Tensor) -> Tensor:
+    """[-1,1] -> voxel ((p+1)*S/2 - 1/2) -> world (affine @ [v;1]): keymorph/utils.py:243-259, 275-291, 320-335."""
+    vox = (points + 1) * sizes.to(points.dtype) / 2 - 0.5
+    return matrix_transform_points(affine.to(points.dtype), vox)
+
+
+def real2norm(points: Tensor, affine: Tensor, sizes: Tensor) -> Tensor:
+    """world -> voxel (affine^-1) -> [-1,1] (2*(v+1/2)/S - 1): keymorph/utils.py:262-272, 294-317, 338-354."""
+    vox = matrix_transform_points(torch.inverse(affine.to(points.dtype)), points)
+    return 2 * (vox + 0.5) / sizes.to(points.dtype) - 1
+
+
+def register_real_world(points_f: Tensor, points_m: Tensor, transform_type: str, shape: Sequence[int],
+                        aff_f: Tensor, aff_m: Tensor, shape_f: Tensor, shape_m: Tensor,
+                        w: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """align_in_real_world_coords=True: fit on the world-space keypoints, and move every query point
+    norm -> world (its own image's affine) -> fitted map -> world -> norm (the other image's affine):
+    keymorph/keypoint_aligners.py:47-66, 116-148 (matrix aligners), 255-268, 431-465 (TPS)."""
+    kind, lam = parse_transform(transform_type)
+    rf, rm = norm2real(points_f, aff_f, shape_f), norm2real(points_m, aff_m, shape_m)
+    g = base_grid(shape, points_f.dtype)
+    flat = norm2real(g.reshape(1, -1, 3), aff_f, shape_f)
+    res: Dict[str, Tensor] = {}
+    if kind in ("affine", "rigid"):
+        fit = affine_fit if kind == "affine" else rigid_fit
+        inv = square(fit(rf, rm, w))
+        fwd = torch.inverse(inv)
+        res["matrix"] = fwd
+        moved = matrix_transform_points(inv, flat)
+        res["points_a"] = real2norm(matrix_transform_points(fwd, rm), aff_f, shape_f)
+    else:
+        lm = torch.full((1,), lam, dtype=points_f.dtype)
+        moved = tps_transform_points(tps_fit(rf, rm, lm, w), rf, flat)
+        res["points_a"] = real2norm(tps_transform_points(tps_fit(rm, rf, lm, w), rm, rm), aff_f, shape_f)
+    res["grid"] = real2norm(moved, aff_m, shape_m).reshape(1, *shape, 3).flip(-1)
+    return res
+
+
+# --------------------------------------------------------------------------
+# a14  one-hot encodings
+# --------------------------------------------------------------------------
+def one_hot(seg: Tensor) -> Tensor:
+    """(N,1,D,H,W) integer labels -> (N,C,D,H,W), C = max label + 1: keymorph/utils.py:200-205."""
+    return F.one_hot(seg)[:, 0].permute(0, 4, 1, 2, 3)
+
+
+def one_hot_subsampled_pair(seg1: Tensor, seg2: Tensor, subsample_num: int = 14):
+    """keymorph/utils.py:208-240: channels = (np.random.choice of) the labels both maps contain, in that order."""
+    import numpy as np
+    shared = np.intersect1d(np.unique(seg1.numpy()), np.unique(seg2.numpy()), assume_unique=True)
+    chosen = np.random.choice(shared, subsample_num, replace=False) if len(shared) > subsample_num else shared
+
+    def enc(seg):
+        return torch.stack([(seg[:, 0] == int(v)).float() for v in chosen], dim=1)
+    return enc(seg1), enc(seg2)
 
 
 def keymorph_forward(backbone, img_f: Tensor, img_m: Tensor, transform_type: str,

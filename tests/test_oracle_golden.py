@@ -280,3 +280,57 @@ def test_keypoint_weighting_training_gradients(tt):
     assert rel(sd["final_conv.weight"].grad, w[f"train::{tt}::gradfull::final_conv.weight"]) < 2e-2
     assert rel(sd["final_conv.bias"].grad, w[f"train::{tt}::gradfull::final_conv.bias"]) < 2e-2
     assert rel(sd["encoders.0.basic_module.SingleConv1.conv.weight"].grad, w[f"train::{tt}::gradfull::enc0"]) < 2e-2
+
+
+# --------------------------------------------------------------------------
+# round 2: real-world-coordinate alignment, one-hot encodings, full gradient vectors
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["affine", "rigid", "tps_10", "tps_1000"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_real_world_alignment(name, weighted):
+    """keypoint_aligners.py:47-66, 116-148, 255-268, 431-465 with non-identity voxel->world matrices and
+    different fixed / moving shapes."""
+    g = golden("realworld_small.npz")
+    pf, pm = T(g["pf"]), T(g["pm"])
+    w = T(g["w"]) if weighted else None
+    aff_f, aff_m, sf, sm = T(g["aff_f"]), T(g["aff_m"]), T(g["shape_f"]), T(g["shape_m"])
+    close(O.norm2real(pf, aff_f, sf), g["pf_real"], 1e-5)
+    close(O.real2norm(O.norm2real(pf, aff_f, sf), aff_f, sf), g["pf_back"], 1e-5)
+    close(O.real2norm(O.norm2real(pm, aff_m, sm), aff_f, sf), g["pm_in_f"], 1e-5)
+    r = O.register_real_world(pf, pm, name, (6, 7, 8), aff_f, aff_m, sf, sm, w)
+    tag = name + ("_w" if weighted else "")
+    tol = 2e-4 if name.startswith("tps") else 2e-5      # mm-scale TPS systems: LAPACK blocking shows at 1e-4
+    close(r["grid"], g[f"{tag}::grid"], tol)
+    close(r["points_a"], g[f"{tag}::points_a"], tol)
+    if "matrix" in r:
+        close(r["matrix"], g[f"{tag}::matrix"], 2e-5, 2e-5)
+
+
+def test_one_hot_encodings():
+    """keymorph/utils.py:200-240 with the reference's np.random draw."""
+    g = golden("onehot_small.npz")
+    close(O.one_hot(T(g["seg"], torch.int64)).float(), g["one_hot"], 0, 0)
+    s1, s2 = T(g["seg1"], torch.int64), T(g["seg2"], torch.int64)
+    for num in (5, 14, 9):
+        np.random.seed(int(g[f"sub{num}::seed"][0]))
+        a, b = O.one_hot_subsampled_pair(s1, s2, num)
+        close(a, g[f"sub{num}::a"], 0, 0)
+        close(b, g[f"sub{num}::b"], 0, 0)
+
+
+@pytest.mark.parametrize("tag,levels,trunc,size", [("tunet16", 4, 1, 16), ("unet16", 4, 0, 16), ("kinkfree", 3, 1, 8)])
+def test_backbone_full_gradients(tag, levels, trunc, size):
+    """Every parameter-gradient tensor of the tiny backbones (gradients_tiny.npz), oracle autograd vs the reference's."""
+    g = golden("gradients_tiny.npz")
+    seed = 300 if tag != "kinkfree" else 1000 + int(g["kinkfree::seed"][0])
+    sd = seeded_state_dict(unet_shapes(8, 8, levels=levels, trunc=trunc or None), seed)
+    assert abs(sd_checksum(sd) - float(g[f"{tag}::sdsum"])) < 1e-6 * float(g[f"{tag}::sdsum"])
+    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+    y = O.unet3d_forward(sd, T(g[f"{tag}::x"]), levels, trunc, 8)
+    close(y, g[f"{tag}::out"], 2e-5, 1e-4)
+    (y * T(g[f"{tag}::cot"])).sum().backward()
+    worst = 0.0
+    for k, v in sd.items():
+        ref = T(g[f"{tag}::grad::{k}"]).double()
+        worst = max(worst, float((v.grad.double() - ref).norm() / (ref.norm() + 1e-30)))
+    assert worst < 1e-4, worst

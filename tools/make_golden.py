@@ -439,11 +439,357 @@ def gen_augment():
     print("augment_small.npz", len(d), "arrays")
 
 
+def _world_affines(g):
+    """Two different voxel->world matrices (anisotropic spacing, a small rotation, an origin): (1, 4, 4) each."""
+    def one(spacing, angle, origin):
+        c, s_ = np.cos(angle), np.sin(angle)
+        R = torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+        A = torch.eye(4)
+        A[:3, :3] = R @ torch.diag(torch.tensor(spacing, dtype=torch.float32))
+        A[:3, 3] = torch.tensor(origin, dtype=torch.float32)
+        return A[None]
+    return one((1.0, 1.2, 0.9), 0.15, (-4.0, 3.0, 1.5)), one((1.1, 0.8, 1.3), -0.1, (2.0, -1.0, 0.5))
+
+
+def gen_realworld():
+    """align_in_real_world_coords=True (keypoint_aligners.py:47-66, 134-148, 255-268, 431-465; utils.py:243-354):
+    the three aligners on point sets, and KeyMorph(align_keypoints_in_real_world_coords=True) on the e2e_tiny pair."""
+    from keymorph.utils import (convert_points_norm2real, convert_points_real2norm, convert_points_norm2voxel,
+                                convert_points_voxel2norm)
+    g = torch.Generator().manual_seed(31)
+    d = {}
+    aff_f, aff_m = _world_affines(g)
+    d["aff_f"], d["aff_m"] = npy(aff_f), npy(aff_m)
+    K = 14
+    shape5 = (1, 1, 6, 7, 8)
+    shape_f = torch.tensor([6.0, 7.0, 8.0])
+    shape_m = torch.tensor([8.0, 6.0, 7.0])
+    pf = torch.rand(1, K, 3, generator=g) * 1.6 - 0.8
+    A = torch.eye(3) + 0.12 * torch.randn(3, 3, generator=g)
+    pm = pf @ A.T + 0.08 * torch.randn(1, 1, 3, generator=g) + 0.03 * torch.randn(1, K, 3, generator=g)
+    w = torch.rand(1, K, generator=g)
+    w = w / w.sum()
+    d["pf"], d["pm"], d["w"], d["shape_f"], d["shape_m"] = npy(pf), npy(pm), npy(w), npy(shape_f), npy(shape_m)
+    d["pf_real"] = npy(convert_points_norm2real(pf, aff_f, shape_f))
+    d["pf_voxel"] = npy(convert_points_norm2voxel(pf, shape_f))
+    d["pf_back"] = npy(convert_points_real2norm(convert_points_norm2real(pf, aff_f, shape_f), aff_f, shape_f))
+    d["pm_in_f"] = npy(convert_points_real2norm(convert_points_norm2real(pm, aff_m, shape_m), aff_f, shape_f))
+    d["pf_vox2norm"] = npy(convert_points_voxel2norm(convert_points_norm2voxel(pf, shape_f), shape_f))
+    common = dict(dim=3, align_in_real_world_coords=True, aff_f=aff_f, aff_m=aff_m, shape_f=shape_f, shape_m=shape_m)
+
+    def make(name, pm_, pf_, wt):
+        if name == "affine":
+            return AffineKeypointAligner(points_m=pm_, points_f=pf_, w=wt, **common)
+        if name == "rigid":
+            return RigidKeypointAligner(points_m=pm_, points_f=pf_, w=wt, **common)
+        return TPS(points_m=pm_, points_f=pf_, lmbda=torch.tensor(float(name[4:])).repeat(1), w=wt, **common)
+
+    for name in ("affine", "rigid", "tps_10", "tps_1000"):
+        for wt, wtag in ((None, ""), (w, "_w")):
+            al = make(name, pm, pf, wt)
+            if name in ("affine", "rigid"):
+                d[f"{name}{wtag}::matrix"] = npy(al.transform_matrix)
+            d[f"{name}{wtag}::grid"] = npy(al.get_flow_field(shape5))
+            d[f"{name}{wtag}::points_a"] = npy(al.get_forward_transformed_points(pm))
+            d[f"{name}{wtag}::points_inv"] = npy(al.get_inverse_transformed_points(pf))
+        pf_ = pf.clone().requires_grad_(True)
+        pm_ = pm.clone().requires_grad_(True)
+        grid = make(name, pm_, pf_, None).get_flow_field(shape5)
+        cot = torch.randn(grid.shape, generator=torch.Generator().manual_seed(8))
+        (grid * cot).sum().backward()
+        d[f"{name}::gridcot"], d[f"{name}::dpf"], d[f"{name}::dpm"] = npy(cot), npy(pf_.grad), npy(pm_.grad)
+
+    # through KeyMorph.forward (model.py:163-170, 230-268) on the e2e_tiny pair and weights
+    e = np.load(os.path.join(OUT, "e2e_tiny.npz"))
+    img_f, img_m = torch.from_numpy(e["img_f"]), torch.from_numpy(e["img_m"])
+    sd = {k[4:]: torch.from_numpy(e[k]) for k in e.files if k.startswith("sd::")}
+    net = make_tunet(16, 8)
+    net.load_state_dict(sd, strict=True)
+    km = KeyMorph(net, 16, 3, max_train_keypoints=None, align_keypoints_in_real_world_coords=True).eval()
+    with torch.no_grad():
+        rr = km(img_f, img_m, transform_type=["rigid", "affine", "tps_10"], return_aligned_points=True,
+                aff_f=aff_f, aff_m=aff_m)
+    for tt in ("rigid", "affine", "tps_10"):
+        d[f"km::{tt}::grid"] = npy(rr[tt]["grid"])
+        d[f"km::{tt}::points_a"] = npy(rr[tt]["points_a"])
+    km.train()
+    for tt in ("affine", "tps_10"):
+        km.zero_grad()
+        r = km(img_f, img_m, transform_type=tt, return_aligned_points=False, aff_f=aff_f, aff_m=aff_m)[tt]
+        mse = loss_ops.MSELoss()(img_f, align_img(r["grid"], img_m))
+        mse.backward()
+        d[f"km_train::{tt}::mse"] = npy(mse)
+        d[f"km_train::{tt}::gradfull::final_conv.weight"] = npy(net.final_conv.weight.grad)
+    np.savez_compressed(os.path.join(OUT, "realworld_small.npz"), **d)
+    print("realworld_small.npz", len(d), "arrays")
+
+
+def gen_onehot():
+    """keymorph/utils.py:200-240: one_hot and one_hot_subsampled_pair (np.random.choice on the shared labels)."""
+    from keymorph.utils import one_hot, one_hot_subsampled_pair
+    g = torch.Generator().manual_seed(13)
+    d = {}
+    seg = torch.randint(0, 5, (2, 1, 4, 5, 6), generator=g)
+    d["seg"], d["one_hot"] = npy(seg), npy(one_hot(seg))
+    lab1 = torch.tensor([0, 2, 3, 5, 7, 8, 11, 12, 17, 20, 21, 30])
+    lab2 = torch.tensor([0, 1, 3, 5, 7, 9, 11, 12, 17, 21, 25, 30, 31])
+    seg1 = lab1[torch.randint(0, len(lab1), (1, 1, 6, 7, 8), generator=g)]
+    seg2 = lab2[torch.randint(0, len(lab2), (1, 1, 6, 7, 8), generator=g)]
+    d["seg1"], d["seg2"] = npy(seg1), npy(seg2)
+    for num, seed in ((5, 3), (14, 4), (9, 5)):
+        np.random.seed(seed)
+        a, b = one_hot_subsampled_pair(seg1, seg2, num)
+        d[f"sub{num}::seed"] = np.asarray([seed])
+        d[f"sub{num}::a"], d[f"sub{num}::b"] = npy(a).astype(np.uint8), npy(b).astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, "onehot_small.npz"), **d)
+    print("onehot_small.npz", len(d), "arrays")
+
+
+def gen_gradients():
+    """Full parameter-gradient vectors (every tensor) of tiny backbones and of the end-to-end training step.
+
+    * `tunet16` / `unet16`: (Truncated)UNet3D, f_maps 8, K = 8, 16^3 input, loss = sum(y * cot).
+    * `kinkfree`: the same TruncatedUNet3D on an input for which NO pre-ReLU value (fp64) lies within `margin` of 0
+      (searched over seeds here), so that no implementation can flip a ReLU mask: gradients must agree to rounding.
+    * `e2e16`: KeyMorph.forward + align_img + MSE (+ Dice), 16^3, affine / tps_1, full gradients."""
+    import torch.nn as nn
+    d = {}
+
+    def pre_relu_margin(net, x):
+        vals = []
+        hooks = [m.register_forward_pre_hook(lambda mod, inp: vals.append(float(inp[0].double().abs().min())))
+                 for m in net.modules() if isinstance(m, nn.ReLU)]      # pre-hook: the ReLUs are in-place
+        with torch.no_grad():
+            net(x)
+        for h in hooks:
+            h.remove()
+        return min(vals)
+
+    def record(tag, net, x, seed_cot):
+        net.train()
+        net.zero_grad()
+        y = net(x)
+        cot = torch.randn(y.shape, generator=torch.Generator().manual_seed(seed_cot))
+        (y * cot).sum().backward()
+        d[f"{tag}::x"], d[f"{tag}::out"], d[f"{tag}::cot"] = npy(x), npy(y), npy(cot)
+        for k, p in net.named_parameters():
+            d[f"{tag}::grad::{k}"] = npy(p.grad)
+
+    x16 = blob_volume((16, 16, 16), 61)
+    for tag, net in (("tunet16", make_tunet(8, 8)), ("unet16", make_unet(8, 8))):
+        sd = seeded_state_dict(net.state_dict(), 300)
+        net.load_state_dict(sd, strict=True)
+        d[f"{tag}::sdsum"] = np.float64(sd_checksum(sd))
+        record(tag, net, x16, 5)
+
+    # kink-free: search (input seed, weight seed) for the largest fp64 margin
+    best = None
+    net = make_tunet(8, 8, levels=3).double()
+    for seed in range(400):
+        sd = seeded_state_dict(net.state_dict(), 1000 + seed)
+        net.load_state_dict({k: v.double() for k, v in sd.items()}, strict=True)
+        x = blob_volume((8, 8, 8), 2000 + seed).double()
+        m = pre_relu_margin(net, x)
+        if best is None or m > best[0]:
+            best = (m, seed)
+        if m > 2e-4:
+            break
+    margin, seed = best
+    print("kink-free margin", margin, "seed", seed)
+    net = make_tunet(8, 8, levels=3)
+    sd = seeded_state_dict(net.state_dict(), 1000 + seed)
+    net.load_state_dict(sd, strict=True)
+    d["kinkfree::margin"] = np.float64(margin)
+    d["kinkfree::seed"] = np.asarray([seed])
+    d["kinkfree::sdsum"] = np.float64(sd_checksum(sd))
+    record("kinkfree", net, blob_volume((8, 8, 8), 2000 + seed), 6)
+
+    # end to end at 16^3 (weights stored: the tests rebuild them from the same seeded recipe, checksum guards)
+    K = 8
+    img_f = blob_volume((16, 16, 16), 71)
+    M = torch.eye(4)[None].clone()
+    M[0, :3, :3] += torch.tensor([[0.05, 0.08, -0.03], [-0.06, -0.04, 0.05], [0.02, -0.07, 0.06]])
+    M[0, :3, 3] = torch.tensor([0.06, -0.05, 0.04])
+    flow = AffineTransform(matrix=M, dim=3).get_flow_field(img_f.shape)
+    img_m = align_img(flow, img_f)
+    seg_f = torch.stack([(img_f[0, 0] > t).float() for t in (0.0, 0.35, 0.6)])[None]
+    seg_f = torch.cat([seg_f[:, :-1] - seg_f[:, 1:], seg_f[:, -1:]], 1)
+    seg_m = align_img(flow, seg_f)
+    d["e2e16::img_f"], d["e2e16::img_m"] = npy(img_f), npy(img_m)
+    d["e2e16::seg_f"], d["e2e16::seg_m"] = npy(seg_f), npy(seg_m)
+    net = make_tunet(K, 8)
+    sd = seeded_state_dict(net.state_dict(), 310)
+    net.load_state_dict(sd, strict=True)
+    d["e2e16::sdsum"] = np.float64(sd_checksum(sd))
+    km = KeyMorph(net, K, 3, max_train_keypoints=None).train()
+    for tt in ("affine", "rigid", "tps_1"):
+        for loss_name in (("mse", "dice") if tt == "affine" else ("mse",)):
+            km.zero_grad()
+            r = km(img_f, img_m, transform_type=tt, return_aligned_points=False)[tt]
+            if loss_name == "mse":
+                loss = loss_ops.MSELoss()(img_f, align_img(r["grid"], img_m))
+            else:
+                loss = loss_ops.DiceLoss()(align_img(r["grid"], seg_m), seg_f)
+            loss.backward()
+            d[f"e2e16::{tt}::{loss_name}::loss"] = npy(loss)
+            d[f"e2e16::{tt}::{loss_name}::grid"] = npy(r["grid"])
+            for k, p in net.named_parameters():
+                d[f"e2e16::{tt}::{loss_name}::grad::{k}"] = npy(p.grad)
+    np.savez_compressed(os.path.join(OUT, "gradients_tiny.npz"), **d)
+    print("gradients_tiny.npz", len(d), "arrays")
+
+
+def gen_weighted_subsample():
+    """Training with weight_keypoints='power', a TPS transform and max_train_keypoints < num_keypoints
+    (keymorph/model.py:209-222: points AND weights are subsampled with one np.random.choice draw)."""
+    g = np.load(os.path.join(OUT, "e2e_tiny.npz"))
+    K = 16
+    img_f, img_m = torch.from_numpy(g["img_f"]), torch.from_numpy(g["img_m"])
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}
+    d = {}
+    for weighting in ("power", None):
+        net = make_tunet(K, 8)
+        net.load_state_dict(sd, strict=True)
+        km = KeyMorph(net, K, 3, max_train_keypoints=6, weight_keypoints=weighting).train()
+        np.random.seed(17)
+        r = km(img_f, img_m, transform_type="tps_1", return_aligned_points=True)["tps_1"]
+        mse = loss_ops.MSELoss()(img_f, align_img(r["grid"], img_m))
+        mse.backward()
+        t = str(weighting)
+        d[f"{t}::points_f"], d[f"{t}::points_m"] = npy(r["points_f"]), npy(r["points_m"])
+        if weighting:
+            d[f"{t}::weights"] = npy(r["points_weights"])
+        d[f"{t}::grid"], d[f"{t}::points_a"], d[f"{t}::mse"] = npy(r["grid"]), npy(r["points_a"]), npy(mse)
+        d[f"{t}::gradfull::final_conv.weight"] = npy(net.final_conv.weight.grad)
+        d[f"{t}::gradfull::final_conv.bias"] = npy(net.final_conv.bias.grad)
+    d["np_seed"] = np.asarray([17])
+    np.savez_compressed(os.path.join(OUT, "weighted_subsample.npz"), **d)
+    print("weighted_subsample.npz", len(d), "arrays")
+
+
+def gen_trainstep():
+    """Two iterations of scripts/train.py:39-176 composed from the reference's own functions (loader dict ->
+    one_hot_subsampled_pair -> random_affine_augment -> KeyMorph.forward -> align_img img + seg -> MSE / Dice ->
+    backward -> torch.optim.Adam), with the script's seeds, for both loss branches; plus the checkpoint the
+    loop would write after step 1 (run.py:588-602 keys).  The loader is the torchio-free dict shape the loop reads."""
+    from keymorph.utils import one_hot_subsampled_pair
+    from keymorph.augmentation import random_affine_augment
+    d = {}
+    K, S = 8, 16
+    g = torch.Generator().manual_seed(91)
+    subjects = []
+    for i in range(2):
+        img = blob_volume((S, S, S), 400 + i)
+        lab = torch.zeros((1, 1, S, S, S), dtype=torch.int64)
+        for j, t in enumerate((0.2, 0.4, 0.6, 0.8)):
+            lab[img > t] = j + 1
+        aff = torch.eye(4)[None].clone()
+        aff[0, :3, 3] = torch.tensor([1.0 * i, -2.0, 0.5])
+        subjects.append({"img": {"data": img, "affine": aff}, "seg": {"data": lab}})
+        d[f"sub{i}::img"], d[f"sub{i}::seg"], d[f"sub{i}::affine"] = npy(img), npy(lab).astype(np.uint8), npy(aff)
+    for loss_fn in ("mse", "dice"):
+        net = make_tunet(K, 8)
+        sd = seeded_state_dict(net.state_dict(), 320)
+        net.load_state_dict(sd, strict=True)
+        d["sdsum"] = np.float64(sd_checksum(sd))
+        km = KeyMorph(net, K, 3, max_train_keypoints=None).train()
+        opt = torch.optim.Adam(km.parameters(), lr=1e-3)
+        torch.manual_seed(23)
+        np.random.seed(23)
+        for step in range(2):
+            fixed, moving = subjects[step % 2], subjects[(step + 1) % 2]
+            img_f, img_m = fixed["img"]["data"], moving["img"]["data"]
+            aff_f, aff_m = fixed["img"]["affine"], moving["img"]["affine"]
+            seg_f, seg_m = one_hot_subsampled_pair(fixed["seg"]["data"].long(), moving["seg"]["data"].long(), 3)
+            img_f, img_m, seg_f, seg_m = img_f.float(), img_m.float(), seg_f.float(), seg_m.float()
+            img_m, seg_m, aug = random_affine_augment(img_m, seg=seg_m, max_random_params=(0.2, 0.2, 3.1416, 0.1),
+                                                      scale_params=0.3, return_affine_matrix=True)
+            aff_m = torch.bmm(aff_m, aug)
+            opt.zero_grad()
+            r = km(img_f, img_m, transform_type="affine", return_aligned_points=False, aff_f=aff_f, aff_m=aff_m)["affine"]
+            img_a = align_img(r["grid"], img_m)
+            seg_a = align_img(r["grid"], seg_m)
+            mse = loss_ops.MSELoss()(img_f, img_a)
+            dice = loss_ops.DiceLoss()(seg_a, seg_f)
+            loss = mse if loss_fn == "mse" else dice
+            loss.backward()
+            t = f"{loss_fn}::step{step}"
+            d[f"{t}::aug_matrix"], d[f"{t}::img_m_aug"] = npy(aug), npy(img_m)
+            d[f"{t}::seg_f"], d[f"{t}::seg_m_aug"] = npy(seg_f).astype(np.uint8), npy(seg_m)
+            d[f"{t}::mse"], d[f"{t}::softdiceloss"] = npy(mse), npy(dice)
+            d[f"{t}::grid"] = npy(r["grid"])
+            d[f"{t}::grad::final_conv.weight"] = npy(net.final_conv.weight.grad)
+            opt.step()
+            d[f"{t}::after::final_conv.weight"] = npy(net.final_conv.weight)
+            d[f"{t}::after::enc0"] = npy(net.encoders[0].basic_module.SingleConv1.conv.weight)
+            if step == 0:
+                state = {"epoch": 1, "args": None, "state_dict": km.backbone.state_dict(), "optimizer": opt.state_dict()}
+                d[f"{loss_fn}::ckpt_keys"] = np.asarray(sorted(state.keys()))
+                d[f"{loss_fn}::ckpt_sd_keys"] = np.asarray(list(state["state_dict"].keys()))
+                d[f"{loss_fn}::ckpt_opt_step"] = np.asarray([float(v["step"]) for v in state["optimizer"]["state"].values()])
+    np.savez_compressed(os.path.join(OUT, "trainstep_tiny.npz"), **d)
+    print("trainstep_tiny.npz", len(d), "arrays")
+
+
+def gen_cfg1():
+    """BASELINE.json configs[0]: the example_data_half pair (scripts/hyperparameters.py:4-11 resizes to 128^3), 128
+    keypoints, affine aligner, reference CPU path.  The intensity images are not in the mount: intensity
+    = label / 13 from example_data_half/seg_m/*.nii.gz, nearest-down-sampled 256^3 -> 128^3 (every second voxel).
+    The fixture holds the two 128^3 label maps (uint8, data) and what the reference computes for them with the
+    seeded TruncatedUNet3D(f_maps 32) weights: keypoints, matrix, losses, sub-sampled grid / warped volume, and
+    summaries of every parameter gradient."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from keymorph_amd.io.nifti import read_nifti
+    d = {}
+    labs = []
+    for i, name in enumerate(("IXI_001_128x128x128.nii.gz", "IXI_002_128x128x128.nii.gz")):
+        arr, aff = read_nifti(os.path.join(REF, "example_data_half", "seg_m", name), dtype=None)
+        lab = np.ascontiguousarray(np.asarray(arr)[::2, ::2, ::2]).astype(np.uint8)
+        assert lab.shape == (128, 128, 128) and lab.max() == 13
+        labs.append(lab)
+        d[f"label_{i}"], d[f"affine_{i}"] = lab, aff
+    K = 128
+    img_f = torch.from_numpy(labs[0].astype(np.float32) / 13.0)[None, None]
+    img_m = torch.from_numpy(labs[1].astype(np.float32) / 13.0)[None, None]
+    seg_f = torch.stack([torch.from_numpy((labs[0] == c).astype(np.float32)) for c in range(14)])[None]
+    seg_m = torch.stack([torch.from_numpy((labs[1] == c).astype(np.float32)) for c in range(14)])[None]
+    net = make_tunet(K, 32)
+    sd = seeded_state_dict(net.state_dict(), 23)
+    net.load_state_dict(sd, strict=True)
+    d["sdsum"] = np.float64(sd_checksum(sd))
+    torch.set_num_threads(8)
+    km = KeyMorph(net, K, 3, max_train_keypoints=None).train()
+    import time
+    t0 = time.time()
+    r = km(img_f, img_m, transform_type="affine", return_aligned_points=True)["affine"]
+    img_a = align_img(r["grid"], img_m)
+    seg_a = align_img(r["grid"], seg_m)
+    mse = loss_ops.MSELoss()(img_f, img_a)
+    dice = loss_ops.DiceLoss()(seg_a, seg_f)
+    mse.backward()
+    d["ref_seconds_fwd_bwd_8_threads"] = np.asarray([time.time() - t0])
+    d["points_f"], d["points_m"], d["points_a"] = npy(r["points_f"]), npy(r["points_m"]), npy(r["points_a"])
+    d["matrix"], d["mse"], d["softdiceloss"] = npy(r["matrix"]), npy(mse), npy(dice)
+    with torch.no_grad():
+        d["harddiceloss"] = npy(loss_ops.DiceLoss(hard=True)(seg_a, seg_f, ign_first_ch=True))
+    d["grid_sub8"] = npy(r["grid"][:, ::8, ::8, ::8])
+    d["img_a_sub4"] = npy(img_a[:, :, ::4, ::4, ::4])
+    for k, p in net.named_parameters():
+        gflat = p.grad.reshape(-1)
+        d[f"gradsum::{k}"] = npy(torch.cat([gflat.sum()[None], gflat.abs().sum()[None], gflat.norm()[None], gflat[:8]]))
+    d["gradfull::final_conv.bias"] = npy(net.final_conv.bias.grad)
+    d["gradfull::enc0"] = npy(net.encoders[0].basic_module.SingleConv1.conv.weight.grad)
+    np.savez_compressed(os.path.join(OUT, "cfg1_example_half_128.npz"), **d)
+    print("cfg1_example_half_128.npz", len(d), "arrays; reference fwd+bwd", float(d["ref_seconds_fwd_bwd_8_threads"][0]), "s")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = {"ops": gen_ops, "backbones": gen_backbones, "e2e": gen_e2e, "groupwise": gen_groupwise,
             "tps_illcond": gen_tps_illcond, "augment": gen_augment, "weighted": gen_weighted,
-            "groupwise_truth": gen_groupwise_truth}
+            "groupwise_truth": gen_groupwise_truth, "realworld": gen_realworld, "onehot": gen_onehot,
+            "gradients": gen_gradients, "weighted_subsample": gen_weighted_subsample, "trainstep": gen_trainstep,
+            "cfg1": gen_cfg1}
     for name in (sys.argv[1:] or list(gens)):      # e.g. `make_golden.py augment` regenerates one fixture
         torch.manual_seed(0)
         np.random.seed(0)
