@@ -97,10 +97,24 @@ def test_real_world_through_keymorph_forward():
     with torch.no_grad():
         rr = km(img_f, img_m, transform_type=["rigid", "affine", "tps_10"], return_aligned_points=True,
                 aff_f=aff_f, aff_m=aff_m)
+    # The backbone's keypoints are clumped (std 0.1) and the fit runs on mm coordinates, so 1e-6 keypoint rounding
+    # differences are amplified ~100x in the grid: the reference's own affine grid is 3.0e-4 from the all-fp64
+    # restatement here (rigid 3e-6, tps_10 1.4e-5).  As for the groupwise grids ("keypoint noise floor") the
+    # two factors are checked separately: our keypoints equal the reference's at the fp32 rounding level, and the
+    # aligner is exact (fp64 oracle) for the keypoints it was given; the reference's grid within 5e-4 as a sanity bound.
+    close(rr["affine"]["points_f"], e["affine::points_f"], 2e-6)
+    close(rr["affine"]["points_m"], e["affine::points_m"], 2e-6)
+    pf64, pm64 = rr["affine"]["points_f"].cpu().double(), rr["affine"]["points_m"].cpu().double()
+    s64 = torch.tensor([32.0, 32.0, 32.0], dtype=torch.float64)
     for tt in ("rigid", "affine", "tps_10"):
-        tol = 3e-4 if tt.startswith("tps") else 1e-4
-        close(rr[tt]["grid"], g[f"km::{tt}::grid"], tol)
-        close(rr[tt]["points_a"], g[f"km::{tt}::points_a"], 5 * tol)
+        exact = O.register_real_world(pf64, pm64, tt, (32, 32, 32), aff_f.cpu().double(), aff_m.cpu().double(), s64, s64)
+        tol = 3e-5 if tt.startswith("tps") else 1e-5
+        close(rr[tt]["grid"], exact["grid"].float(), tol)
+        close(rr[tt]["points_a"], exact["points_a"].float(), tol)
+        close(rr[tt]["grid"], g[f"km::{tt}::grid"], 5e-4)
+        close(rr[tt]["points_a"], g[f"km::{tt}::points_a"], 5e-4)
+        print(tt, "real-world grid vs fp64 oracle on our keypoints", float((rr[tt]["grid"].cpu().double() - exact["grid"]).abs().max()),
+              "vs the reference", float((rr[tt]["grid"].cpu() - T(g[f"km::{tt}::grid"])).abs().max()))
     with pytest.raises(KeyError):
         km(img_f, img_m, transform_type="affine", return_aligned_points=False)       # aff_f / aff_m are required
     km.train()

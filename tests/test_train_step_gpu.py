@@ -109,7 +109,9 @@ def test_two_training_iterations_and_resume(loss_fn, tmp_path):
         for name, p in (("final_conv.weight", net.final_conv.weight),
                         ("enc0", net.encoders[0].basic_module.SingleConv1.conv.weight)):
             d = (p.detach().cpu() - T(g[f"{t}::after::{name}"])).abs()
-            assert float((d > 2e-5).float().mean()) < (2e-3 if step == 0 else 5e-2), (t, name, float(d.max()))
+            # (step 1: Adam's second update divides by sqrt(v) of two gradients that already differ at the 1e-4 level)
+            assert float((d > (2e-5 if step == 0 else 1e-4)).float().mean()) < (2e-3 if step == 0 else 5e-2), \
+                (t, name, float(d.max()))
             assert float(d.max()) <= 2.5e-3 * (step + 1), (t, name, float(d.max()))
         if step == 0:
             path = tmp_path / "epoch1_trained_model.pth.tar"

@@ -78,7 +78,8 @@ def sd_checksum(sd):
 
 
 def npy(t):
-    return t.detach().cpu().numpy()
+    # a COPY: .numpy() of a CPU tensor shares its memory, and parameters / .grad buffers are updated in place later
+    return np.array(t.detach().cpu().numpy(), copy=True)
 
 
 def blob_volume(shape, seed):
