@@ -79,3 +79,107 @@ def jdlessthan0(disp, as_percentage=False):
     """Number (or fraction) of voxels with a non-positive Jacobian determinant (loss_ops.py:237-242)."""
     st = _jacdet(disp, False)[1]
     return float(st[2] / st[3]) if as_percentage else int(st[2])
+
+
+# --------------------------------------------------------------------------
+# groupwise evaluation metrics over files or tensor stacks (keymorph/loss_ops.py:406-551; callers
+# scripts/groupwise_register_eval.py:478-515): the pairwise / per-grid averages, HIP losses underneath
+# --------------------------------------------------------------------------
+def _load_file(path, device=None):
+    """loss_ops.py:406-412 (.npy; NIfTI through keymorph_amd.io.read_nifti instead of nibabel); lands on the GPU."""
+    import numpy as np
+    path = str(path)
+    if path.endswith(".nii") or path.endswith(".nii.gz"):
+        from .io import read_nifti
+        arr = read_nifti(path)[0]
+    elif path.endswith(".npy"):
+        arr = np.load(path)
+    else:
+        raise ValueError("File format not supported")
+    return torch.tensor(arr).to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+
+
+def _item(batch, i):
+    return _load_file(batch[i]) if isinstance(batch[0], (str, bytes)) or hasattr(batch[0], "__fspath__") else batch[i:i + 1]
+
+
+class _AvgPairwiseLoss(torch.nn.Module):
+    """Mean of metric_fn over all unordered pairs (loss_ops.py:415-435)."""
+
+    def __init__(self, metric_fn):
+        super().__init__()
+        self.metric_fn = metric_fn
+
+    def forward(self, batch_of_imgs):
+        loss, num = 0, 0
+        for i in range(len(batch_of_imgs)):
+            for j in range(i + 1, len(batch_of_imgs)):
+                loss = loss + self.metric_fn(_item(batch_of_imgs, i), _item(batch_of_imgs, j))
+                num += 1
+        return loss / num
+
+
+class MSEPairwiseLoss(_AvgPairwiseLoss):
+    def __init__(self):
+        super().__init__(MSELoss().forward)
+
+
+class SoftDicePairwiseLoss(_AvgPairwiseLoss):
+    def __init__(self):
+        super().__init__(DiceLoss().forward)
+
+
+class HardDicePairwiseLoss(_AvgPairwiseLoss):
+    def __init__(self):
+        super().__init__(DiceLoss(hard=True).forward)
+
+
+class MultipleAvgSegPairwiseMetric(torch.nn.Module):
+    """Several pairwise segmentation metrics in one sweep over the files (loss_ops.py:499-527).  'hausd' (scipy /
+    skimage surface distances on the host) is outside the registration path and not provided."""
+
+    def __init__(self):
+        super().__init__()
+        self.name2fn = {"harddice": DiceLoss(hard=True).forward,
+                        "harddiceroi": DiceLoss(hard=True, return_regions=True).forward,
+                        "softdice": DiceLoss().forward}
+
+    def forward(self, batch_of_imgs, fn_names):
+        for name in fn_names:
+            if name not in self.name2fn:
+                raise NotImplementedError(f"metric '{name}' is not part of the MI355X registration path")
+        res, num = {name: 0 for name in fn_names}, 0
+        for i in range(len(batch_of_imgs)):
+            for j in range(i + 1, len(batch_of_imgs)):
+                a, b = _item(batch_of_imgs, i), _item(batch_of_imgs, j)
+                for name in fn_names:
+                    res[name] = res[name] + self.name2fn[name](a, b)
+                num += 1
+        return {name: res[name] / num for name in fn_names}
+
+
+class MultipleAvgGridMetric(torch.nn.Module):
+    """Jacobian-determinant metrics averaged over the grids of a group (loss_ops.py:530-551)."""
+
+    def __init__(self):
+        super().__init__()
+        self.name2fn = {"jdstd": jdstd, "jdlessthan0": jdlessthan0}
+
+    def forward(self, batch_of_grids, fn_names):
+        res = {name: 0 for name in fn_names}
+        for i in range(len(batch_of_grids)):
+            grid = _item(batch_of_grids, i).float()
+            gp = grid.permute(0, 4, 1, 2, 3)
+            for name in fn_names:
+                res[name] += self.name2fn[name](gp)
+        return {name: res[name] / len(batch_of_grids) for name in fn_names}
+
+
+class AvgJDStd(MultipleAvgGridMetric):
+    def forward(self, batch_of_grids):
+        return super().forward(batch_of_grids, ["jdstd"])["jdstd"]
+
+
+class AvgJDLessThan0(MultipleAvgGridMetric):
+    def forward(self, batch_of_grids):
+        return super().forward(batch_of_grids, ["jdlessthan0"])["jdlessthan0"]

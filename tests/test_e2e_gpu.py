@@ -267,3 +267,39 @@ def test_training_trajectories_agree_across_arithmetic_modes():
         dev[mode] = abs((curves[mode][0] - curves[mode][-1]) - (ref[0] - ref[-1])) / (ref[0] - ref[-1])
         assert dev[mode] < 0.10, (mode, dev[mode], curves[mode], ref)
     assert dev["f16x3"] < 3 * dev["bf16x6"] + 0.02, dev
+
+
+def test_groupwise_evaluation_products_on_disk(tmp_path):
+    """f-3: the files scripts/groupwise_register_eval.py:346-431, 478-527 leaves behind for one group -- aligned images /
+    segmentations as .npy, metrics-{type}.json, keypoints -- against what the reference's own functions produce for the
+    same 3-subject group (tests/golden/groupwise_eval_tiny.npz)."""
+    import json
+    from keymorph_amd.io import evaluate_group
+    g, ge = golden("groupwise_tiny.npz"), golden("groupwise_eval_tiny.npz")
+    km = make_model(16, seeded_state_dict(unet_shapes(16, 8, trunc=1), 200)).eval()
+    os.makedirs(tmp_path / "img_m")
+    os.makedirs(tmp_path / "seg_m")
+    for i in range(3):
+        np.savez(tmp_path / "img_m" / f"img_m_{i:03}.npz", img=g[f"img_{i}"])
+        np.savez(tmp_path / "seg_m" / f"seg_m_{i:03}.npz", seg=ge[f"seg_{i}"].astype(np.float32))
+    out = evaluate_group(km, tmp_path, ["affine", "tps_1"], DEV, metrics=("mse", "softdice", "harddice", "harddiceroi",
+                                                                           "jdstd", "jdlessthan0"), num_iters=5)
+    for tt in ("affine", "tps_1"):
+        for i in range(3):
+            assert (tmp_path / f"img_a_{tt}" / f"img_a_{tt}_{i:03}.npy").exists()
+            assert (tmp_path / f"seg_a_{tt}" / f"seg_a_{tt}_{i:03}.npy").exists()
+            assert (tmp_path / "registration_results" / f"{tt}_grid_{i:03}.npy").exists()
+        # aligned volumes: the keypoint noise floor of the groupwise grids (see _grid_ok) times the image gradient
+        close(np.load(tmp_path / f"img_a_{tt}" / f"img_a_{tt}_001.npy"), ge[f"{tt}::img_a_1"], 5e-4)
+        close(np.load(tmp_path / f"seg_a_{tt}" / f"seg_a_{tt}_001.npy"), ge[f"{tt}::seg_a_1"], 5e-3)
+        ref = json.loads(str(ge[f"{tt}::metrics_json"]))
+        got = json.load(open(tmp_path / f"metrics-{tt}.json"))
+        assert sorted(got) == sorted(ref) and got == out[tt]
+        for k in ("mse", "softdice", "harddice", "jdstd"):
+            assert abs(got[k] - ref[k]) <= 1e-4 + 1e-3 * abs(ref[k]), (tt, k, got[k], ref[k])
+        assert abs(got["jdlessthan0"] - ref["jdlessthan0"]) <= 2
+        close(got["harddiceroi"], ref["harddiceroi"], 2e-3)
+        # five rounds of alignment to the running mean of CLUMPED keypoints amplify 1e-7 keypoint rounding differences
+        # to 1e-3 relative (the reference's own fp32 result is that far from its fp64 restatement, cf. _grid_ok)
+        close(np.load(tmp_path / f"points_a-rot0-{tt}.npy"), ge[f"{tt}::points_a0"], 5e-3, 5e-3)
+    close(np.load(tmp_path / "points_m-rot0.npy"), ge["points_m0"], 2e-6)

@@ -1,0 +1,107 @@
+"""GPU, two ranks: the data-parallel step (pairs sharded by rank, ONE sum all-reduce of the flat gradient bucket, fused
+Adam with 1/world) and the sharded groupwise registration (subjects partitioned, one padded all-gather of keypoints).
+With >= 2 devices: one rank per GPU over RCCL (backend "nccl"), the production layout of BASELINE configs[3] / [4].
+On a 1-GPU box the two ranks share device 0 over gloo (RCCL refuses two ranks on one device; test hooks
+KEYMORPH_DIST_BACKEND / KEYMORPH_SHARE_GPU in parallel.init_distributed) -- same code path above the collective."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(dev):
+    from keymorph_amd.model import KeyMorph
+    from keymorph_amd.unet3d.model import TruncatedUNet3D
+    torch.manual_seed(23)
+    net = TruncatedUNet3D(1, 16, 1, final_sigmoid=False, f_maps=8, layer_order="gcr", num_groups=8, num_levels=3,
+                          is_segmentation=False, conv_padding=1)
+    return KeyMorph(net, 16, 3, max_train_keypoints=None).to(dev).train()
+
+
+def _step(km, flat, opt, pairs, tt="tps_1"):
+    from keymorph_amd import ops
+    flat.zero_grad()
+    img_f, img_m = torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs])
+    res = km(img_f, img_m, transform_type=tt, return_aligned_points=False)[tt]
+    loss, _ = ops.warp_mse(img_m, res["grid"], img_f)
+    loss.backward()
+    scale = flat.allreduce_grads()
+    opt.step(scale)
+    return float(loss.detach())
+
+
+def _worker(rank, world, port, shared, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if shared:
+        os.environ.update(KEYMORPH_DIST_BACKEND="gloo", KEYMORPH_SHARE_GPU="1")
+    from keymorph_amd import parallel, synthetic
+    r, local, w = parallel.init_distributed()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    km = _model(dev)
+    flat = parallel.FlatParams(km.parameters())
+    flat.broadcast(0)
+    opt = parallel.FusedAdam(flat, lr=1e-3)
+    pairs = [synthetic.make_pair(24, 100 * rank + i, dev) for i in range(2)]       # bench.py's seed rule
+    losses = [_step(km, flat, opt, pairs) for _ in range(2)]
+    # sharded groupwise registration: 3 subjects over 2 ranks
+    stack = torch.cat([synthetic.blob_volume(24, 50 + i, dev) for i in range(3)])
+    km.eval()
+    with torch.no_grad():
+        res = km.groupwise_register(stack, transform_type=["affine"], device=dev, save_results_to_disk=False,
+                                    num_iters=2, log_to_console=False)["affine"]
+    out[rank] = dict(losses=losses, flat=flat.flat.cpu(), backend=torch.distributed.get_backend(),
+                     ranks=torch.distributed.get_world_size(), mine=res["grid_subjects"],
+                     grids=res["groupgrids"].cpu(), pts=res["grouppoints_a"].cpu(), device=str(dev))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_and_sharded_groupwise():
+    from keymorph_amd import parallel, synthetic
+    world = 2
+    shared = torch.cuda.device_count() < 2
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), shared, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    assert a["ranks"] == 2 and a["backend"] == ("gloo" if shared else "nccl")
+    assert (a["device"], b["device"]) == (("cuda:0", "cuda:0") if shared else ("cuda:0", "cuda:1"))
+    assert torch.equal(a["flat"], b["flat"])                 # identical parameters after two synchronised steps
+    # single-process reference: the same 4 pairs as ONE batch (mean of per-pair losses = average of the rank gradients)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    km = _model(dev)
+    flat = parallel.FlatParams(km.parameters())
+    opt = parallel.FusedAdam(flat, lr=1e-3)
+    pairs = [synthetic.make_pair(24, 100 * r + i, dev) for r in range(2) for i in range(2)]
+    ref_losses = [_step(km, flat, opt, pairs) for _ in range(2)]
+    for k in range(2):
+        assert abs(0.5 * (a["losses"][k] + b["losses"][k]) - ref_losses[k]) < 1e-5 * max(1.0, abs(ref_losses[k]))
+    d = (a["flat"] - flat.flat.cpu()).abs()
+    assert float((d > 2e-5).float().mean()) < 5e-3, float(d.max())      # Adam: +-lr flips of ~0 gradient components only
+    # groupwise: each rank produced the grids of its own subjects, the gathered keypoints agree everywhere
+    assert a["mine"] == [0, 1] and b["mine"] == [2]
+    assert a["grids"].shape[0] == 2 and b["grids"].shape[0] == 1
+    assert torch.equal(a["pts"], b["pts"])
+    km.eval()
+    stack = torch.cat([synthetic.blob_volume(24, 50 + i, dev) for i in range(3)])
+    # (the single-process model has taken the same two steps, to within the Adam flips above)
+    with torch.no_grad():
+        ref = km.groupwise_register(stack, transform_type=["affine"], device=dev, save_results_to_disk=False, num_iters=2,
+                                    log_to_console=False)["affine"]
+    got = torch.cat([a["grids"], b["grids"]])
+    np.testing.assert_allclose(got.numpy(), ref["groupgrids"].cpu().numpy(), atol=5e-3)

@@ -784,13 +784,69 @@ def gen_cfg1():
     print("cfg1_example_half_128.npz", len(d), "arrays; reference fwd+bwd", float(d["ref_seconds_fwd_bwd_8_threads"][0]), "s")
 
 
+def gen_groupwise_eval():
+    """scripts/groupwise_register_eval.py:375-527 composed from the reference's own functions on a 3-subject group:
+    grids from KeyMorph.groupwise_register, aligned images / segmentations, and the metrics dictionary it would write
+    to metrics-{type}.json (MSEPairwiseLoss, MultipleAvgSegPairwiseMetric, MultipleAvgGridMetric)."""
+    import json
+    g = np.load(os.path.join(OUT, "groupwise_tiny.npz"))
+    d = {}
+    K = 16
+    net = make_tunet(K, 8)
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 200), strict=True)
+    km = KeyMorph(net, K, 3, max_train_keypoints=None).eval()
+    types = ["affine", "tps_1"]
+    with tempfile.TemporaryDirectory() as td:
+        img_dir, seg_dir, res_dir = (os.path.join(td, n) for n in ("img_m", "seg_m", "registration_results"))
+        for p in (img_dir, seg_dir, res_dir):
+            os.makedirs(p)
+        for i in range(3):
+            img = torch.from_numpy(g[f"img_{i}"])
+            seg = torch.stack([(img[0, 0] > t).float() for t in (-1.0, 0.3, 0.5, 0.7)])[None]
+            seg = torch.cat([seg[:, :-1] - seg[:, 1:], seg[:, -1:]], 1)
+            d[f"seg_{i}"] = npy(seg).astype(np.uint8)
+            np.savez(os.path.join(img_dir, f"img_m_{i:03}.npz"), img=npy(img))
+            np.savez(os.path.join(seg_dir, f"seg_m_{i:03}.npz"), seg=npy(seg))
+        with torch.no_grad():
+            res = km.groupwise_register(img_dir, transform_type=types, device="cpu", save_results_to_disk=True,
+                                        save_dir=res_dir, plot=False, num_iters=5, log_to_console=False,
+                                        num_resolutions_for_itkelastix=None)
+        img_paths = sorted(os.path.join(img_dir, f) for f in os.listdir(img_dir))
+        seg_paths = sorted(os.path.join(seg_dir, f) for f in os.listdir(seg_dir))
+        for tt in types:
+            grids = sorted(os.path.join(res_dir, f) for f in os.listdir(res_dir) if f.startswith(tt))
+            ia, sa = [], []
+            for i in range(3):
+                grid = torch.tensor(np.load(grids[i]))
+                img_a = align_img(grid, torch.tensor(np.load(img_paths[i])["img"]))
+                seg_a = align_img(grid, torch.tensor(np.load(seg_paths[i])["seg"]))
+                ia.append(os.path.join(td, f"img_a_{tt}_{i:03}.npy"))
+                sa.append(os.path.join(td, f"seg_a_{tt}_{i:03}.npy"))
+                np.save(ia[-1], npy(img_a))
+                np.save(sa[-1], npy(seg_a))
+                if i == 1:
+                    d[f"{tt}::img_a_1"], d[f"{tt}::seg_a_1"] = npy(img_a), npy(seg_a)
+            m = {"mse": loss_ops.MSEPairwiseLoss()(ia).item()}
+            sm = loss_ops.MultipleAvgSegPairwiseMetric()(sa, ["softdice", "harddice", "harddiceroi"])
+            sm["harddice"] = (1 - sm["harddice"]).item()
+            sm["harddiceroi"] = (1 - sm["harddiceroi"]).tolist()
+            sm["softdice"] = (1 - sm["softdice"]).item()
+            gm = loss_ops.MultipleAvgGridMetric()(grids, ["jdstd", "jdlessthan0"])
+            m = m | sm | gm
+            d[f"{tt}::metrics_json"] = np.asarray(json.dumps(m, sort_keys=True))
+            d[f"{tt}::points_a0"] = npy(res[tt]["grouppoints_a"][0])
+        d["points_m0"] = npy(res[types[0]]["grouppoints_m"][0])
+    np.savez_compressed(os.path.join(OUT, "groupwise_eval_tiny.npz"), **d)
+    print("groupwise_eval_tiny.npz", len(d), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = {"ops": gen_ops, "backbones": gen_backbones, "e2e": gen_e2e, "groupwise": gen_groupwise,
             "tps_illcond": gen_tps_illcond, "augment": gen_augment, "weighted": gen_weighted,
             "groupwise_truth": gen_groupwise_truth, "realworld": gen_realworld, "onehot": gen_onehot,
             "gradients": gen_gradients, "weighted_subsample": gen_weighted_subsample, "trainstep": gen_trainstep,
-            "cfg1": gen_cfg1}
+            "cfg1": gen_cfg1, "groupwise_eval": gen_groupwise_eval}
     for name in (sys.argv[1:] or list(gens)):      # e.g. `make_golden.py augment` regenerates one fixture
         torch.manual_seed(0)
         np.random.seed(0)
