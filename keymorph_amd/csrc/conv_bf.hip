@@ -24,6 +24,7 @@
 //   * the filter is pre-packed as [cin/8][term][step][half][cout][8] 16-bit values, so a B fragment is one
 //     512-byte-per-half-wave global_load_dwordx4 from L2, prefetched through a register ring;
 //   * the epilogue can emit the (sum, sum of squares) per channel that the next GroupNorm needs.
+#include <cstdio>
 #include <cstdlib>
 #include "common.h"
 #include <type_traits>
@@ -405,104 +406,120 @@ __global__ __launch_bounds__(BF_TPB, ((MR == 2 && NT == 2 && TERMS == 3) ? 3 : 2
 // conv3_fwd_g_kernel -- the same implicit GEMM with the staging taken off the critical path (round 2).
 // What bounded conv3_fwd_bf_kernel was its staging: per chunk every thread ran six serial load -> wait -> normalise ->
 // split -> ds_write chains through registers, 0.7 of an MFMA phase long, while the matrix pipe idled (SQ: 46 % busy).
-// Here one 512-thread workgroup per CU owns a 32 x 8 x 4 output brick (halo 34 x 10 x 6 = 2040 voxels):
-//   * the raw fp32 halo of chunk c+1 is copied HBM -> LDS by global_load_lds_dwordx4 (16 bytes per lane, no staging
-//     registers, no VALU, latency fully overlapped) while the MFMAs of chunk c run;
+// Here ONE persistent 512-thread workgroup per CU walks a list of 32 x 8 x 4 output bricks (halo 34 x 10 x 6 = 2040
+// voxels) as one pipeline of (brick, 8-channel chunk) stages:
+//   * the raw fp32 halo of the NEXT stage -- the next chunk, or chunk 0 of the next brick -- is copied HBM -> LDS by
+//     global_load_lds_dwordx4 (16 bytes per lane, no staging registers, no VALU) while the MFMAs of this stage run, so
+//     neither a chunk nor a brick starts with an exposed HBM round trip, and a brick's output stores drain under the
+//     next brick's first chunk;
 //   * a short LDS -> LDS conversion phase (GroupNorm scale/shift, ReLU, zero padding, range scale, fp16 hi/lo split: the
 //     same arithmetic, so results are bit-identical to conv3_fwd_bf_kernel) turns it into the two fragment images;
 //   * eight waves = 4 output planes x 2 row halves, 4 rows x NT cout tiles each (128 accumulator registers for NT = 2):
 //     two waves per SIMD keep the matrix pipe fed, every B fragment is reused by 4 rows, the halo re-read factor is
-//     1.99 instead of 2.66.
-// LDS: raw stage 2040 x 32 B + two fragment images 2040 x 16 B = 130 560 B.  Ordinary global loads (the B ring) and
-// LDS-DMA share one in-order vmcnt queue and hipcc drains it completely at the first use of a loaded register while a
-// DMA is in flight, so the DMA burst of chunk c+1 is issued at tap-pair step 10 of chunk c, AFTER the last B fragments
-// of chunk c have been issued and waited for: steps 10-13 (4 x 24 MFMAs per wave) cover its latency and no register
-// load is outstanding behind it.
+//     1.99 instead of 2.66.  ZP (Cout <= 16, z-paired weights): waves = 2 plane pairs x 4 row quarters, the N tile is
+//     (16 couts x 2 planes) over the pair's 4-plane input window, 18 tap-pair steps.
+// LDS: raw stage 2040 x 32 B + two fragment images 2040 x 16 B (reused as 8 x 8 KB epilogue tiles) + the DMA offset
+// table 16 KB = 147 200 B.
 constexpr int GTY = 8, GTZ = 4;
 constexpr int GHY = GTY + 2, GHZ = GTZ + 2, GPL = HX * GHY * GHZ;      // 2040 halo voxels
 constexpr int G_TPB = 512;
-#ifndef KMH_G_APREF
-#define KMH_G_APREF 0     // 1: A fragments of step s+1 prefetched into a second register set (measured 4 % SLOWER, see below)
-#endif
 constexpr int G_SLOTS = 2 * GPL;                                       // 16-byte slots of the raw stage
 constexpr int G_AUX = 0;     // (nt, aux = 2, measured 12 % slower: neighbouring bricks share halo lines through L2)
 constexpr int G_NLD = (G_SLOTS + G_TPB - 1) / G_TPB;                   // 8 LDS-DMA instructions per thread and chunk
 constexpr int G_NCV = (GPL + G_TPB - 1) / G_TPB;                       // 4 voxels converted per thread and chunk
 constexpr int G_OFF_BYTES = G_NLD * G_TPB * 4;                         // the DMA source offsets live in LDS, not in VGPRs
-constexpr int G_LDS_BYTES = G_SLOTS * 16 + 2 * GPL * 16 + G_OFF_BYTES; // 130 560 + 16 384
+constexpr int G_IMG_BYTES = 8 * 32 * 64 * 4;                           // fragment images (65 280 B) / epilogue tiles (8 x 8 KB)
+constexpr int G_LDS_BYTES = G_SLOTS * 16 + G_IMG_BYTES + G_OFF_BYTES;  // 65 280 + 65 536 + 16 384 = 147 200
 
 typedef __attribute__((address_space(3))) void* kmh_lds_ptr;
 typedef const __attribute__((address_space(1))) void* kmh_glb_ptr;
 
-template <int NT>
+template <int NT, bool ZP>
 __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16x8* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int D, int H, int W, int Cin,
     int Cout, int CoutP, int relu_in, int relu_out, int tiles_x, int tiles_y, int tiles_z, int tiles_zp,
     const float* __restrict__ ascale, const float* __restrict__ wscale, double* __restrict__ stats_partial,
-    int in_blocked, const float* __restrict__ addend) {
-  constexpr int TERMS = 2, MR = 4;
+    int in_blocked, const float* __restrict__ addend, int total_items, long long* __restrict__ trace) {
+  constexpr int TERMS = 2, MR = ZP ? 2 : 4;
+  constexpr int NST = ZP ? NSTEP_Z : NSTEP;
+  static_assert(!ZP || NT == 1, "z-paired tiles are for Cout <= 16");
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   float4* sRaw = reinterpret_cast<float4*>(gsm);                        // [GPL][2]: 8 fp32 channels per halo voxel
   bf16x8* sIn = reinterpret_cast<bf16x8*>(gsm + G_SLOTS * 16);          // [TERMS][GPL]
-  int* sOff = reinterpret_cast<int*>(gsm + G_SLOTS * 16 + 2 * GPL * 16);   // [G_NLD][512] DMA source offsets (elements)
+  int* sOff = reinterpret_cast<int*>(gsm + G_SLOTS * 16 + G_IMG_BYTES);     // [G_NLD][512] DMA source offsets (elements)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform by construction: keep it (and wz, wy, the
   const int li = lane & 31, lh = lane >> 5;                    // DMA's LDS bases, the per-wave step tests) in SGPRs
   const int n = blockIdx.z;
-  const int ncog = (Cout + 32 * NT - 1) / (32 * NT);
-  const int item = xcd_remap(blockIdx.x, gridDim.x);
-  const int cog = item % ncog, brick = item / ncog;
-  // 8 x 8 (y, z) patches of bricks per XCD, as in conv3_fwd_bf_kernel
+  const int ncog = ZP ? 1 : (Cout + 32 * NT - 1) / (32 * NT);
   const int tyz = (tiles_y + 7) >> 3;
-  const int lz8 = brick & 7, ly8 = (brick >> 3) & 7, patch = brick >> 6;
-  const int pyi = patch % tyz, rest = patch / tyz;
-  const int pzi = rest % tiles_zp, bx = rest / tiles_zp;
-  const int by = pyi * 8 + ly8, bz = pzi * 8 + lz8;
-  if (by >= tiles_y || bz >= tiles_z) return;
-  const int x0 = bx * TX, y0 = by * GTY, z0 = bz * GTZ;
-  const int co0 = cog * (32 * NT);
-  const int wz = wv >> 1, wy = (wv & 1) * MR;
+  // work list of this workgroup: virtual block ids blockIdx.x, + gridDim.x, ... of a launch with `total_items` blocks,
+  // mapped like conv3_fwd_bf_kernel maps its blocks (cout groups adjacent, 8 x 8 (y, z) brick patches per XCD;
+  // gridDim.x is a multiple of 8, so every id of the list lands on this workgroup's XCD)
+  struct Item { int cog, bx, by, bz; };
+  auto decode = [&](int vb, Item& it) -> bool {
+    const int item = xcd_remap(vb, total_items);
+    it.cog = item % ncog;
+    const int brick = item / ncog;
+    const int lz8 = brick & 7, ly8 = (brick >> 3) & 7, patch = brick >> 6;
+    const int pyi = patch % tyz, rest = patch / tyz;
+    const int pzi = rest % tiles_zp;
+    it.bx = rest / tiles_zp; it.by = pyi * 8 + ly8; it.bz = pzi * 8 + lz8;
+    return it.by < tiles_y && it.bz < tiles_z;             // patches are padded to 8 x 8
+  };
+  auto next_item = [&](int& vb, Item& it) -> bool {        // advance to the next real brick of the list
+    for (vb += gridDim.x; vb < total_items; vb += gridDim.x)
+      if (decode(vb, it)) return true;
+    return false;
+  };
+  int vb = (int)blockIdx.x - (int)gridDim.x;
+  Item cur, nxt;
+  if (!next_item(vb, cur)) return;
 
-  f32x16 acc[MR][NT];
-#pragma unroll
-  for (int m = 0; m < MR; ++m)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
-
+  const int wz = ZP ? 2 * (wv >> 2) : wv >> 1;             // first output plane of the wave
+  const int wy = ZP ? (wv & 3) * MR : (wv & 1) * MR;
   const float sA = ascale ? ascale[0] : 1.f;
   const float desc = (ascale ? ascale[1] : 1.f) * (wscale ? wscale[1] : 1.f);
   const int nchunk = Cin / KC;
   const int vrow = (wz * GHY + wy) * HX + li;
-
-  // LDS-DMA descriptors: 16-byte slot e = r * 512 + tid holds half (e & 1) of halo voxel e >> 1; padding voxels fetch
-  // the clamped in-volume voxel (any valid address: the conversion writes zeros for them)
   const long long vox = (long long)D * H * W;
   const float* xb = in_blocked ? x + (long long)n * nchunk * vox * KC : x + (long long)n * vox * Cin;
   const long long chunk_stride = in_blocked ? vox * KC : KC;
+
+  // LDS-DMA descriptors of a brick: 16-byte slot e = r * 512 + tid holds half (e & 1) of halo voxel e >> 1; padding
+  // voxels fetch the clamped in-volume voxel (any valid address: the conversion writes zeros for them)
+  auto fill_offsets = [&](const Item& it) {
+    const int x0 = it.bx * TX, y0 = it.by * GTY, z0 = it.bz * GTZ;
+    int t_ = tid;                     // opaque: the 24 halo coordinates of this thread's slots are recomputed per brick
+    asm volatile("" : "+v"(t_));      // instead of living in (spilled) registers across the whole pipeline
 #pragma unroll
-  for (int r = 0; r < G_NLD; ++r) {
-    const int e = r * G_TPB + tid, v = (e >> 1) < GPL ? (e >> 1) : GPL - 1;
-    const int lx = v % HX, ly = (v / HX) % GHY, lz = v / (HX * GHY);
-    int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - 1;
-    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
-    gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
-    gz = gz < 0 ? 0 : (gz > D - 1 ? D - 1 : gz);
-    sOff[e] = ((gz * H + gy) * W + gx) * (in_blocked ? KC : Cin) + 4 * (e & 1);      // read back by this thread only
-  }
-  // conversion descriptors: voxel v = tid + 512 i; bit i of cv_in = inside the volume
-  unsigned cv_in = 0;
+    for (int r = 0; r < G_NLD; ++r) {
+      const int e = r * G_TPB + t_, v = (e >> 1) < GPL ? (e >> 1) : GPL - 1;
+      const int lx = v % HX, ly = (v / HX) % GHY, lz = v / (HX * GHY);
+      int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - 1;
+      gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+      gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+      gz = gz < 0 ? 0 : (gz > D - 1 ? D - 1 : gz);
+      sOff[e] = ((gz * H + gy) * W + gx) * (in_blocked ? KC : Cin) + 4 * (e & 1);      // read back by this thread only
+    }
+  };
+  auto inside_bits = [&](const Item& it) -> unsigned {     // bit i: voxel tid + 512 i of the halo is inside the volume
+    const int x0 = it.bx * TX, y0 = it.by * GTY, z0 = it.bz * GTZ;
+    unsigned bits = 0;
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
 #pragma unroll
-  for (int i = 0; i < G_NCV; ++i) {
-    const int v = tid + i * G_TPB;
-    const int lx = v % HX, ly = (v / HX) % GHY, lz = v / (HX * GHY);
-    const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - 1;
-    const bool in = (v < GPL) && ((unsigned)gx < (unsigned)W) && ((unsigned)gy < (unsigned)H) && ((unsigned)gz < (unsigned)D);
-    cv_in |= (in ? 1u : 0u) << i;
-  }
-  auto dma_chunk = [&](int ch) {                    // this wave's 8 KB of the chunk's halo
+    for (int i = 0; i < G_NCV; ++i) {
+      const int v = t_ + i * G_TPB;
+      const int lx = v % HX, ly = (v / HX) % GHY, lz = v / (HX * GHY);
+      const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - 1;
+      const bool in = (v < GPL) && ((unsigned)gx < (unsigned)W) && ((unsigned)gy < (unsigned)H) && ((unsigned)gz < (unsigned)D);
+      bits |= (in ? 1u : 0u) << i;
+    }
+    return bits;
+  };
+  auto dma_chunk = [&](int ch) {                    // this wave's 8 KB of a chunk's halo (offsets of the brick in sOff)
     const float* base = xb + ch * chunk_stride;
 #pragma unroll
     for (int r = 0; r < G_NLD; ++r) {
@@ -511,22 +528,20 @@ __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
                                          (kmh_lds_ptr)(sRaw + r * G_TPB + wv * 64), 16, 0, G_AUX);
     }
   };
-  // ---- B fragments straight from L2 through a register ring BD tap-pair steps deep; the halo DMA of chunk c+1 runs
-  // underneath the MFMAs of chunk c.  Measured facts that shape this loop (192 -> 64 at 128^3, one launch):
-  //   * a 65 KB halo burst needs ~5 us to land (~12 GB/s per CU for 32-byte NDHWC pieces): issued BD steps before the
-  //     end of the chunk it was the whole difference between this kernel (7.5 ms) and the same kernel without staging
-  //     (5.7 ms) -- so the DMA has to start at the beginning of the chunk and trickle;
+
+  // ---- B fragments straight from L2 through a register ring BD tap-pair steps deep.  Measured facts that shape the loop:
   //   * loads and LDS-DMA of one wave share ONE vmcnt queue, and hipcc drains it completely at every use of a loaded
   //     register while a DMA is in flight: the B loads are therefore inline asm with hand-counted waits;
-  //   * a count may only rely on the order of the B loads among themselves (LDS-DMA completions can overtake them):
-  //     "vmcnt(number of B loads issued after the needed one)" is exact without a DMA in flight and merely
-  //     stricter with one;
-  //   * each wave issues its share of the DMA (8 x 1 KB) in ONE step, wave w in step w: its own next B loads queue
-  //     behind 8 KB only, the two waves of a SIMD never stall in the same step, and the last piece has 6 steps to land.
-  const int boff = lh * CoutP + co0 + li;
-  constexpr int BD = NT == 1 ? 4 : (KMH_G_APREF ? 2 : 4);            // (prefetched A fragments take 64 registers, see below)
+  //   * a count may only rely on the order of the B loads among themselves (an LDS-DMA can complete before an older
+  //     load: counting DMAs as "younger, still in flight" gave wrong results): "vmcnt(number of B loads issued after
+  //     the needed one)" is exact without a DMA in flight and merely stricter with one;
+  //   * each wave issues its share of a DMA (8 x 1 KB) in ONE step, wave w in step w: its own next B loads queue
+  //     behind 8 KB only, the two waves of a SIMD never stall in the same step, and the last piece has 6+ steps to land;
+  //   * SQ counters put the matrix pipe at 55 % busy at an effective 1.93 GHz for the first (non-persistent) version of
+  //     this kernel (46 % for conv3_fwd_bf_kernel), i.e. 1.12 PF of fp16 MFMA under the power cap.
+  constexpr int BD = 4;
   constexpr int BL = 2 * NT;                                         // B loads per step
-  const long long step_stride = 2ll * CoutP, term_stride = (long long)NSTEP * step_stride;
+  const long long step_stride = 2ll * CoutP, term_stride = (long long)NST * step_stride;
   bf16x8 bq[BD][NT][TERMS];
   long long o0 = 0;
   auto b_issue = [&](int slot) {
@@ -541,163 +556,214 @@ __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
     o0 += step_stride;
   };
 
+  // static priority for the second-dispatched half: the two waves of a SIMD (w, w + 4) are arbitrated by priority, then
+  // AGE, and at equal priority the older wave finished every chunk ~7k cycles ahead of its partner and idled at the
+  // barrier (cycle stamps, KMH_G_TRACE); MI355X_MICROARCH.md "Two waves per SIMD", item 4
+  if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+  fill_offsets(cur);
   dma_chunk(0);
-  for (int ch = 0; ch < nchunk; ++ch) {
-    float csc[8], csh[8];
+  unsigned cv_in = inside_bits(cur);
+  int tr_n = 0;                                            // KMH_G_TRACE: s_memtime stamps of workgroup 0, wave 0
+  auto stamp = [&]() {
+    if (trace && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0 && tr_n < 240) trace[tr_n++] = __builtin_readcyclecounter();
+  };
+  for (;;) {
+    stamp();                                               // brick start
+    const bool more = next_item(vb, nxt);
+    const int co0 = cur.cog * (32 * NT);
+    const int boff = lh * CoutP + co0 + li;
+    f32x16 acc[MR][NT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      csc[j] = (scale ? scale[n * Cin + ch * KC + j] : 1.f) * sA;
-      csh[j] = (scale ? shift[n * Cin + ch * KC + j] : 0.f) * sA;
-    }
-    // this wave's DMAs of the chunk have landed; after the barrier everybody's have -- and every wave is done with
-    // the MFMAs of the previous chunk, so the fragment images may be overwritten
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // first BD steps of fragments: in flight during the conversion
-    o0 = (long long)ch * TERMS * term_stride + boff;
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
-    for (int d = 0; d < BD; ++d) b_issue(d);
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int i = 0; i < G_NCV; ++i) {
-      const int v = tid + i * G_TPB;
-      if (v < GPL) {
-        const float4 r0 = sRaw[2 * v], r1 = sRaw[2 * v + 1];
-        const float raw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-        const bool in = (cv_in >> i) & 1u;
-        float val[8];
+        for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+      float csc[8], csh[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float t = raw[j] * csc[j] + csh[j];
-          if (relu_in) t = fmaxf(t, 0.f);
-          val[j] = in ? t : 0.f;                         // zero padding AFTER the normalisation
-        }
-        bf16x8 parts[TERMS];
-        split8<TERMS>(val, parts);
-#pragma unroll
-        for (int t = 0; t < TERMS; ++t) sIn[t * GPL + v] = parts[t];
+      for (int j = 0; j < 8; ++j) {
+        csc[j] = (scale ? scale[n * Cin + ch * KC + j] : 1.f) * sA;
+        csh[j] = (scale ? shift[n * Cin + ch * KC + j] : 0.f) * sA;
       }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();      // the fragment images are complete; the raw stage may be overwritten
-    // (opaque copy: keeps the 14 per-step fragment addresses from being hoisted out of the chunk loop into 14 VGPRs)
-    int vr = vrow, lhv = lh;
-    asm volatile("" : "+v"(vr), "+v"(lhv));
-    // KMH_G_APREF = 1 double-buffers the A fragments in registers (the eight ds_read_b128 of step s+1 issued at the start
-    // of step s, B ring 2 deep to pay for the 32 extra registers).  Measured back to back on one box it is 4 % SLOWER
-    // than letting hipcc place each fragment read a few MFMAs before its first use with a 4-deep B ring (192 -> 64 at
-    // 128^3: 8.05-8.14 vs 7.73-7.80 ms; conv3_fwd_bf_kernel 8.43-8.46): the exposed LDS latencies are not what idles the
-    // matrix pipe.  SQ counters put it at 55 % busy at an effective 1.93 GHz (46 % for conv3_fwd_bf_kernel), i.e.
-    // 1.12 PF of fp16 MFMA -- the guide's hand-tuned 256^2 GEMM reaches 1.32-1.47 PF on random operands under the same
-    // power cap, so what is left above this loop is ~15-20 %, not 2x.
-    bf16x8 a[2][MR][TERMS];
-    auto a_issue = [&](int s, int buf) {
-      const int tapA = 2 * s, tapB = (2 * s + 1 > 26) ? 26 : 2 * s + 1;      // padded half-step: zero weights
-      const int offA = ((tapA / 9) * GHY + (tapA / 3) % 3) * HX + tapA % 3;
-      const int offB = ((tapB / 9) * GHY + (tapB / 3) % 3) * HX + tapB % 3;
-      const int abase = vr + (lhv ? offB : offA);
+      // this wave's DMAs of the stage have landed (and its output stores of the previous brick have drained); after the
+      // barrier everybody's have -- and every wave is done with the MFMAs of the previous stage: the fragment images
+      // may be overwritten
+      stamp();                                             // chunk top
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp();                                             // own DMA landed / stores drained
+      __builtin_amdgcn_s_barrier();
+      stamp();                                             // barrier 1 passed
+      // first BD steps of B fragments: in flight during the conversion
+      o0 = (long long)ch * TERMS * term_stride + boff;
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
+      for (int d = 0; d < BD; ++d) b_issue(d);
 #pragma unroll
-        for (int q = 0; q < TERMS; ++q) a[buf][m][q] = sIn[q * GPL + abase + m * HX];
-    };
-    if (KMH_G_APREF) a_issue(0, 0);
+      for (int i = 0; i < G_NCV; ++i) {
+        const int v = tid + i * G_TPB;
+        if (v < GPL) {
+          const float4 r0 = sRaw[2 * v], r1 = sRaw[2 * v + 1];
+          const float raw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+          const bool in = (cv_in >> i) & 1u;
+          float val[8];
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      if (s < 8 && s == wv && ch + 1 < nchunk) dma_chunk(ch + 1);
-      {   // this step's B fragments: leave only the B loads issued after them in flight
-        const int ahead = (s + BD - 1 < NSTEP - 1 ? s + BD - 1 : NSTEP - 1) - s;      // steps already issued beyond s
-        switch (ahead * BL) {
-          case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-          case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-          case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-          case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-          case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-          case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-          case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          for (int j = 0; j < 8; ++j) {
+            float t = raw[j] * csc[j] + csh[j];
+            if (relu_in) t = fmaxf(t, 0.f);
+            val[j] = in ? t : 0.f;                         // zero padding AFTER the normalisation
+          }
+          bf16x8 parts[TERMS];
+          split8<TERMS>(val, parts);
+#pragma unroll
+          for (int t = 0; t < TERMS; ++t) sIn[t * GPL + v] = parts[t];
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (KMH_G_APREF) {
-        if (s + 1 < NSTEP) a_issue(s + 1, (s + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-      } else {
-        a_issue(s, s & 1);
-      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp();                                             // conversion done
+      __builtin_amdgcn_s_barrier();      // the fragment images are complete; the raw stage may be overwritten
+      stamp();                                             // barrier 2 passed
+      // the next stage's halo: the next chunk of this brick, or chunk 0 of the next brick (whose offsets replace this
+      // brick's in the table: every DMA of this brick has been issued by now)
+      const bool last_ch = ch + 1 == nchunk;
+      const bool have_next = !last_ch || more;
+      if (last_ch && more) fill_offsets(nxt);
+      // (opaque copies: keep the per-step fragment addresses from being hoisted out of the loops into 14 + 14 VGPRs)
+      int vr = vrow, lhv = lh;
+      asm volatile("" : "+v"(vr), "+v"(lhv));
+      // (Reading the A fragments of step s+1 into a second register set at the start of step s was measured and dropped:
+      // NT = 2: 4 % slower (and 11 spilled registers); NT = 1 / z-paired tiles, 12 / 6 MFMAs per wave and step: the
+      // tap-pair phase went from 14.5-17k to 16-18k cycles (KMH_G_TRACE).  hipcc's own placement -- each ds_read a few
+      // MFMAs ahead of its first use -- stays.)
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          acc[m][t] = mfma16<TERMS>(a[s & 1][m][1], bq[s % BD][t][0], acc[m][t]);      // smallest terms first, as conv3_fwd_bf_kernel
-          acc[m][t] = mfma16<TERMS>(a[s & 1][m][0], bq[s % BD][t][1], acc[m][t]);
-          acc[m][t] = mfma16<TERMS>(a[s & 1][m][0], bq[s % BD][t][0], acc[m][t]);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + BD < NSTEP) b_issue(s % BD);     // refill the slot just consumed
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  // ---- epilogue: the non-z-paired epilogue of conv3_fwd_bf_kernel with 8 waves
-  float st1[NT], st2[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) st1[t] = st2[t] = 0.f;
-  const long long sbrick = ((long long)n * tiles_z * tiles_y * tiles_x + ((long long)bz * tiles_y + by) * tiles_x + bx);
-  const int gz = z0 + wz;
-  if (gz < D) {
-#pragma unroll
-    for (int m = 0; m < MR; ++m) {
-      const int gy = y0 + wy + m;
-      if (gy >= H) continue;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int co = co0 + 32 * t + li;
-        if (co >= Cout) continue;
-        const float bv = bias ? bias[co] : 0.f;
-        const long long rowoff = ((((long long)n * D + gz) * H + gy) * W) * Cout + co;
-        float* yp = y + rowoff;
-        // the 16 addend values of this (row, cout tile) first, all in flight together (one load -> add -> store chain
-        // per element cost the decoder's skip-channel launches 2.6 ms per step)
-        float ad[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          ad[r] = (addend && gx < W) ? addend[rowoff + (long long)gx * Cout] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (gx < W) {
-            float v = acc[m][t][r] * desc + bv;
-            v += ad[r];
-            if (relu_out) v = fmaxf(v, 0.f);
-            yp[(long long)gx * Cout] = v;
-            st1[t] += v; st2[t] += v * v;
+      for (int s = 0; s < NST; ++s) {
+        if (s < 8 && s == wv && have_next) dma_chunk(last_ch ? 0 : ch + 1);
+        {   // this step's B fragments: leave only the B loads issued after them in flight
+          const int ahead = (s + BD - 1 < NST - 1 ? s + BD - 1 : NST - 1) - s;      // steps already issued beyond s
+          switch (ahead * BL) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int last_tap = ZP ? 35 : 26;
+        const int tapA = 2 * s, tapB = (2 * s + 1 > last_tap) ? last_tap : 2 * s + 1;      // padded half-step: zero weights
+        const int offA = ((tapA / 9) * GHY + (tapA / 3) % 3) * HX + tapA % 3;
+        const int offB = ((tapB / 9) * GHY + (tapB / 3) % 3) * HX + tapB % 3;
+        const int abase = vr + (lhv ? offB : offA);
+        bf16x8 a[MR][TERMS];
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int q = 0; q < TERMS; ++q) a[m][q] = sIn[q * GPL + abase + m * HX];
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            acc[m][t] = mfma16<TERMS>(a[m][1], bq[s % BD][t][0], acc[m][t]);      // smallest terms first, as conv3_fwd_bf_kernel
+            acc[m][t] = mfma16<TERMS>(a[m][0], bq[s % BD][t][1], acc[m][t]);
+            acc[m][t] = mfma16<TERMS>(a[m][0], bq[s % BD][t][0], acc[m][t]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + BD < NST) b_issue(s % BD);     // refill the slot just consumed
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stamp();                                             // steps done
+    }
+
+    // ---- epilogue of the brick (the stores drain under the next brick's first stage).  The accumulators hold one
+    // CHANNEL per lane (32 consecutive channels of a voxel across 32 lanes): stored as they are that is 128 four-byte
+    // store instructions per lane and brick, which cost 56k cycles per brick -- two whole chunks (cycle stamps: the
+    // store path is issue-bound, MI355X_MICROARCH.md "epilogue store tail").  So every wave transposes its tile row by
+    // row through its own 8 KB of the (now idle) fragment-image region and stores 16 bytes per lane: 4x fewer
+    // instructions, whole 64-byte channel runs per 4 lanes.
+    const int x0 = cur.bx * TX, y0 = cur.by * GTY, z0 = cur.bz * GTZ;
+    constexpr int CH = 32 * NT;                                // columns of the wave's tile
+    constexpr int L4 = CH / 4;                                 // lanes per voxel in the transposed view (8 or 16)
+    constexpr int VPI = 64 / L4;                               // voxels per read instruction (8 or 4)
+    const long long sbrick = ((long long)n * tiles_z * tiles_y * tiles_x + ((long long)cur.bz * tiles_y + cur.by) * tiles_x + cur.bx);
+    float* tile = reinterpret_cast<float*>(sIn) + wv * (32 * CH);
+    const int c4 = lane % L4, vx = lane / L4;                  // this lane's column quad and first voxel in the view
+    const int col = 4 * c4;
+    const int pl = ZP ? col >> 4 : 0;                          // ZP: column = (channel, output plane of the pair)
+    const int co = ZP ? (col & 15) : co0 + col;
+    const bool co_ok = co < Cout;                              // Cout % 4 == 0 (launcher)
+    float4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias && co_ok) bv = *reinterpret_cast<const float4*>(bias + co);
+    float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                           // every wave is done with the fragment images
+    const int gz = z0 + wz + pl;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * CH + 32 * t + li] = acc[m][t][r];
+      const int gy = y0 + wy + m;
+      const bool row_ok = gz < D && gy < H && co_ok;
+      const long long rowoff = ((((long long)n * D + gz) * H + gy) * W) * Cout + co;
+      float4 v4[32 / VPI], ad[32 / VPI];
+#pragma unroll
+      for (int k = 0; k < 32 / VPI; ++k) {
+        const int xx = vx + VPI * k;
+        v4[k] = *reinterpret_cast<const float4*>(tile + xx * CH + col);
+        ad[k] = float4{0.f, 0.f, 0.f, 0.f};
+        if (addend && row_ok && x0 + xx < W) ad[k] = *reinterpret_cast<const float4*>(addend + rowoff + (long long)(x0 + xx) * Cout);
+      }
+#pragma unroll
+      for (int k = 0; k < 32 / VPI; ++k) {
+        const int gx = x0 + vx + VPI * k;
+        if (row_ok && gx < W) {
+          float4 o;
+          o.x = v4[k].x * desc + bv.x + ad[k].x; o.y = v4[k].y * desc + bv.y + ad[k].y;
+          o.z = v4[k].z * desc + bv.z + ad[k].z; o.w = v4[k].w * desc + bv.w + ad[k].w;
+          if (relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+          *reinterpret_cast<float4*>(y + rowoff + (long long)gx * Cout) = o;
+          st1[0] += o.x; st2[0] += o.x * o.x; st1[1] += o.y; st2[1] += o.y * o.y;
+          st1[2] += o.z; st2[2] += o.z * o.z; st1[3] += o.w; st2[3] += o.w * o.w;
+        }
       }
     }
-  }
-  if (stats_partial) {
-    __syncthreads();                                     // every wave is done with the LDS images
-    double* sred = reinterpret_cast<double*>(gsm);
+    if (stats_partial) {
+      // per (wave, column) sums -> LDS -> one (sum, sum^2) pair per channel and brick, fixed order (deterministic)
+      double d1[4], d2[4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      double d1 = (double)st1[t], d2 = (double)st2[t];
-      d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
-      if (lh == 0) { sred[((wv * NT + t) * 32 + li) * 2] = d1; sred[((wv * NT + t) * 32 + li) * 2 + 1] = d2; }
-    }
-    __syncthreads();
-    if (tid < 64 * NT) {
-      const int k = tid & 1, c = tid >> 1;               // c = t * 32 + li
-      const int co = co0 + c;
-      if (co < Cout) {
-        double sum = 0.0;
+      for (int j = 0; j < 4; ++j) {
+        d1[j] = (double)st1[j]; d2[j] = (double)st2[j];
 #pragma unroll
-        for (int w8 = 0; w8 < 8; w8 += 2)                // fixed order: (0+1) + (2+3) + ...
-          sum += sred[((w8 * NT) * 32 + c) * 2 + k] + sred[(((w8 + 1) * NT) * 32 + c) * 2 + k];
-        stats_partial[(sbrick * Cout + co) * 2 + k] = sum;
+        for (int o = L4; o < 64; o <<= 1) { d1[j] += __shfl_xor(d1[j], o); d2[j] += __shfl_xor(d2[j], o); }
+      }
+      __syncthreads();                                         // the tiles have been read back
+      double* sred = reinterpret_cast<double*>(sIn);           // [wave][CH][2]  (NOT the raw stage: the next halo lands there)
+      if (lane < L4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sred[((wv * CH) + col + j) * 2] = d1[j]; sred[((wv * CH) + col + j) * 2 + 1] = d2[j]; }
+      }
+      __syncthreads();
+      const int ncol = ZP ? 16 : CH;
+      if (tid < 2 * ncol) {
+        const int k = tid & 1, c = tid >> 1;
+        const int cch = ZP ? c : co0 + c;
+        if (cch < Cout) {
+          double sum = 0.0;
+#pragma unroll
+          for (int w8 = 0; w8 < 8; ++w8) {
+            sum += sred[(w8 * CH + c) * 2 + k];
+            if (ZP) sum += sred[(w8 * CH + 16 + c) * 2 + k];   // the second plane of the pair
+          }
+          stats_partial[(sbrick * Cout + cch) * 2 + k] = sum;
+        }
       }
     }
+    stamp();                                               // epilogue issued
+    if (!more) break;
+    cur = nxt;
+    cv_in = inside_bits(cur);
   }
 }
 
@@ -1333,33 +1399,54 @@ static int launch_fwd_bf(const float* x, const float* scale, const float* shift,
   return KMH_LAUNCH_CHECK();
 }
 
-template <int NT>
+template <int NT, bool ZP>
 static int launch_fwd_g(const float* x, const float* scale, const float* shift, const bf16x8* wp, const float* bias,
                         float* y, int N, int D, int H, int W, int Cin, int Cout, int CoutP, int relu_in, int relu_out,
                         const float* ascale, const float* wscale, double* stats_ws, double* stats_out, hipStream_t s,
                         int in_blocked, const float* addend) {
-  hipError_t e = hipFuncSetAttribute((const void*)conv3_fwd_g_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute((const void*)conv3_fwd_g_kernel<NT, ZP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      G_LDS_BYTES);
   if (e != hipSuccess) return (int)e;
   const int tx = ceil_div(W, TX), ty = ceil_div(H, GTY), tz = ceil_div(D, GTZ);
   const int typ = ceil_div(ty, 8), tzp = ceil_div(tz, 8);
-  dim3 g(tx * typ * tzp * 64 * ceil_div(Cout, 32 * NT), 1, N);
-  conv3_fwd_g_kernel<NT><<<g, G_TPB, G_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in,
-                                                       relu_out, tx, ty, tz, tzp, ascale, wscale,
-                                                       stats_out ? stats_ws : nullptr, in_blocked, addend);
+  const int total = tx * typ * tzp * 64 * (ZP ? 1 : ceil_div(Cout, 32 * NT));      // virtual blocks per sample
+  // persistent workgroups, one per CU: the 256 CUs are shared out over the samples in multiples of 8 (so that every id
+  // of a workgroup's list falls on its own XCD)
+  int wgs = ((256 / (N < 32 ? N : 32)) / 8) * 8;
+  if (wgs < 8) wgs = 8;
+  if (wgs > ((total + 7) / 8) * 8) wgs = ((total + 7) / 8) * 8;
+  dim3 g(wgs, 1, N);
+  static long long* trace = nullptr;                       // KMH_G_TRACE=1 (debug): cycle stamps of workgroup 0 to stderr
+  static const bool tracing = getenv("KMH_G_TRACE") != nullptr;
+  if (tracing && !trace) { if (hipMalloc(&trace, 240 * sizeof(long long)) != hipSuccess) trace = nullptr; }
+  if (tracing && trace) (void)hipMemsetAsync(trace, 0, 240 * sizeof(long long), s);
+  conv3_fwd_g_kernel<NT, ZP><<<g, G_TPB, G_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in,
+                                                           relu_out, tx, ty, tz, tzp, ascale, wscale,
+                                                           stats_out ? stats_ws : nullptr, in_blocked, addend, total,
+                                                           tracing ? trace : nullptr);
+  if (tracing && trace) {
+    long long h[240];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "KMH_G_TRACE NT=%d ZP=%d Cin=%d Cout=%d D=%d:", NT, (int)ZP, Cin, Cout, D);
+    for (int i = 1; i < 240 && h[i]; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+    fprintf(stderr, "\n");
+  }
   if (stats_out)
     kmh_stats::final_kernel<<<dim3(ceil_div(Cout * 2, 256 / kWave), N), 256, 0, s>>>(stats_ws, tx * ty * tz, Cout,
                                                                                   stats_out);
   return KMH_LAUNCH_CHECK();
 }
 
-// the LDS-DMA kernel's preconditions: fp16 split, whole 8-channel chunks, no fused mask operand, standard (not z-paired)
-// weight packing, and enough bricks to fill the chip with ONE 512-thread workgroup per CU
-static bool fwd_g_ok(const float* mask, int N, int D, int H, int W, int Cin, int Cout, int terms) {
+// the LDS-DMA kernel's preconditions: fp16 split, whole 8-channel chunks, no fused mask operand, and enough bricks to
+// give every CU several of them
+static bool fwd_g_ok(const float* mask, const float* addend, int N, int D, int H, int W, int Cin, int Cout, int terms) {
   static const int mode = getenv("KEYMORPH_FWD_G") ? atoi(getenv("KEYMORPH_FWD_G")) : 1;     // 0: off (A/B runs)
-  if (!mode || terms != 2 || mask || (Cin & 7) || use_zpair(Cout)) return false;
+  if (!mode || terms != 2 || mask || (Cin & 7) || (Cout & 3)) return false;
+  if (use_zpair(Cout) && addend) return false;
   if ((long long)D * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31)) return false;          // 32-bit element offsets
-  const long long wgs = (long long)N * ceil_div(W, TX) * ceil_div(H, GTY) * ceil_div(D, GTZ) * ceil_div(Cout, 64);
+  const long long wgs = (long long)N * ceil_div(W, TX) * ceil_div(H, GTY) * ceil_div(D, GTZ) *
+                        (use_zpair(Cout) ? 1 : ceil_div(Cout, 64));
   return wgs >= (mode == 2 ? 1 : 512);
 }
 
@@ -1402,9 +1489,10 @@ KMH_API int kmh_conv3d_fwd_bf(const float* x, const float* scale, const float* s
   // registers plus 8 staging descriptors and is 4 % slower: not instantiated.)
   static const bool no_deep = getenv("KEYMORPH_FWD_NO_DEEP") != nullptr;     // A/B measurements only
   const bool deep = !no_deep && terms == 2 && Cout <= 32 && D >= 16 && (long long)D * H * W >= (1ll << 21);
-  if (fwd_g_ok(mask, N, D, H, W, Cin, Cout, terms)) {
-    if (Cout > 32) return launch_fwd_g<2>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
-    return launch_fwd_g<1>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
+  if (fwd_g_ok(mask, addend, N, D, H, W, Cin, Cout, terms)) {
+    if (use_zpair(Cout)) return launch_fwd_g<1, true>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
+    if (Cout > 32) return launch_fwd_g<2, false>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
+    return launch_fwd_g<1, false>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
   }
   if (use_zpair(Cout)) {   // weights were packed z-paired by kmh_conv3d_pack_weight_bf for this Cout
     if (terms == 2 && deep) return launch_fwd_bf<1, 2, 2, true, 2>(x, scale, shift, mask, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked);
