@@ -48,6 +48,14 @@ int kmh_mse_bwd(const float* a, const float* b, const float* gscale, long long n
 /* fused warp + MSE against `fixed` (same shape as out): writes out and out_loss[0]. */
 int kmh_warp_mse_fwd(const float* x, const float* grid, const float* fixed, float* out, float* out_loss,
                      int N, int C, int D, int H, int W, int Do, int Ho, int Wo, void* ws, void* stream);
+/* the same pass also writes dgrid = d(out_loss)/d(grid) (the MSE cotangent 2 (out - fixed) / count is known inside the
+ * warp): align_img + MSELoss + autograd of both in ONE launch, 36 B per voxel instead of 68 in three; out may be NULL.
+ * -22 when the shape needs the generic sampler (then use the separate entry points). */
+int kmh_warp_mse_fwd_grad(const float* x, const float* grid, const float* fixed, float* out, float* out_loss,
+                          float* dgrid, int N, int C, int D, int H, int W, int Do, int Ho, int Wo, void* ws,
+                          void* stream);
+/* a (n floats, n % 4 == 0) *= g[0], skipped on the device when g[0] == 1 (loss.backward() with the default cotangent) */
+int kmh_scale_unless_one(float* a, long long n, const float* g, void* stream);
 
 /* ---- a13: DiceLoss sums, keymorph/loss_ops.py:43-57.  pred/target (R, V) rows = n*c;
  *      sums (R,3) = {sum t*p, sum p*p, sum t*t}. */

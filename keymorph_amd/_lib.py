@@ -26,6 +26,8 @@ PROTOS = {
     "kmh_mse_fwd": (_i, [_f, _f, _ll, _f, _f, _f]),
     "kmh_mse_bwd": (_i, [_f, _f, _f, _ll, _f, _f]),
     "kmh_warp_mse_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f]),
+    "kmh_warp_mse_fwd_grad": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f]),
+    "kmh_scale_unless_one": (_i, [_f, _ll, _f, _f]),
     "kmh_dice_sums": (_i, [_f, _f, _i, _ll, _f, _f, _f]),
     "kmh_rows_axpby": (_i, [_f, _f, _f, _f, _i, _ll, _f, _f]),
     "kmh_argmax_onehot": (_i, [_f, _i, _i, _ll, _f, _f]),

@@ -62,15 +62,17 @@ __device__ __forceinline__ void gather8(const float* __restrict__ p, const Tap& 
 
 __device__ __forceinline__ float blend8(const float v[8], const Tap& t) {
   const float ax = 1.f - t.fx, ay = 1.f - t.fy, az = 1.f - t.fz;
-  // same association as ATen: value * (wx*wy*wz) summed corner by corner
+  // same association as ATen: value * (wx*wy*wz) summed corner by corner -- as ONE explicit fma chain, so that every
+  // instantiation of every sampler kernel rounds identically (left to -ffp-contract=fast the fused and the plain warp
+  // differed by 1 ulp in 13 % of the voxels)
   float o = v[0] * (ax * ay * az);
-  o += v[1] * (t.fx * ay * az);
-  o += v[2] * (ax * t.fy * az);
-  o += v[3] * (t.fx * t.fy * az);
-  o += v[4] * (ax * ay * t.fz);
-  o += v[5] * (t.fx * ay * t.fz);
-  o += v[6] * (ax * t.fy * t.fz);
-  o += v[7] * (t.fx * t.fy * t.fz);
+  o = fmaf(v[1], t.fx * ay * az, o);
+  o = fmaf(v[2], ax * t.fy * az, o);
+  o = fmaf(v[3], t.fx * t.fy * az, o);
+  o = fmaf(v[4], ax * ay * t.fz, o);
+  o = fmaf(v[5], t.fx * ay * t.fz, o);
+  o = fmaf(v[6], ax * t.fy * t.fz, o);
+  o = fmaf(v[7], t.fx * t.fy * t.fz, o);
   return o;
 }
 
@@ -282,10 +284,14 @@ __device__ __forceinline__ void unstage_rows(float* __restrict__ dst, int cnt, c
   }
 }
 
-template <int MODE, bool FUSE_MSE>
+// FUSE_GRAD (with FUSE_MSE): the loss is mean((out - fixed)^2), whose cotangent 2 (out - fixed) / count is known right
+// here, so the same pass also produces d(loss)/d(grid) -- the rows of the staged grid are overwritten with it and written
+// out like the grid came in.  One launch and 36 B per voxel instead of three (warp, MSE backward, grid backward) and 68.
+template <int MODE, bool FUSE_MSE, bool FUSE_GRAD = false>
 __global__ __launch_bounds__(TPB) void sample_fwd_lc_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ out,
-    const float* __restrict__ fixed, double* __restrict__ partial, int C, int D, int H, int W, long long ovox) {
+    const float* __restrict__ fixed, double* __restrict__ partial, int C, int D, int H, int W, long long ovox,
+    float* __restrict__ dgrid = nullptr, float gcoef = 0.f /* 2 / (N C voxels) */) {
   __shared__ __attribute__((aligned(16))) float sg[TPB * PASSES * 3];
   const int n = blockIdx.y, tid = threadIdx.x;
   const long long vb = (long long)blockIdx.x * (TPB * PASSES);
@@ -313,6 +319,9 @@ __global__ __launch_bounds__(TPB) void sample_fwd_lc_kernel(
         near[u] = (zn * H + yn) * W + xn;
       }
     }
+    float ggx[ILP], ggy[ILP], ggz[ILP];
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) ggx[u] = ggy[u] = ggz[u] = 0.f;
     for (int c = 0; c < C; ++c) {
       const float* p = x + ((long long)n * C + c) * plane;
       const long long ob = ((long long)n * C + c) * ovox + vb;
@@ -327,6 +336,23 @@ __global__ __launch_bounds__(TPB) void sample_fwd_lc_kernel(
         for (int u = 0; u < ILP; ++u) gather8_pairs(p, q[u], v[u]);
 #pragma unroll
         for (int u = 0; u < ILP; ++u) o[u] = blend8(v[u], t[u]);
+        if (FUSE_GRAD) {
+#pragma unroll
+          for (int u = 0; u < ILP; ++u) {
+            const float fx = t[u].fx, fy = t[u].fy, fz = t[u].fz;
+            const float ax = 1.f - fx, ay = 1.f - fy, az = 1.f - fz;
+            const float* w = v[u];
+            // d/dix, d/diy, d/diz of the trilinear blend (ATen grid_sampler_3d_backward), as sample_bwd_grid_lc_kernel
+            const float dx = -w[0] * (ay * az) + w[1] * (ay * az) - w[2] * (fy * az) + w[3] * (fy * az)
+                             - w[4] * (ay * fz) + w[5] * (ay * fz) - w[6] * (fy * fz) + w[7] * (fy * fz);
+            const float dy = -w[0] * (ax * az) - w[1] * (fx * az) + w[2] * (ax * az) + w[3] * (fx * az)
+                             - w[4] * (ax * fz) - w[5] * (fx * fz) + w[6] * (ax * fz) + w[7] * (fx * fz);
+            const float dz = -w[0] * (ax * ay) - w[1] * (fx * ay) - w[2] * (ax * fy) - w[3] * (fx * fy)
+                             + w[4] * (ax * ay) + w[5] * (fx * ay) + w[6] * (ax * fy) + w[7] * (fx * fy);
+            const float go = (tid + (j0 + u) * TPB < cnt) ? (o[u] - fv[u]) * gcoef : 0.f;
+            ggx[u] += dx * go; ggy[u] += dy * go; ggz[u] += dz * go;
+          }
+        }
       } else {
 #pragma unroll
         for (int u = 0; u < ILP; ++u) o[u] = p[near[u]];
@@ -336,10 +362,21 @@ __global__ __launch_bounds__(TPB) void sample_fwd_lc_kernel(
         const int l = tid + (j0 + u) * TPB;
         if (l < cnt) {
           if (FUSE_MSE) { const float d = o[u] - fv[u]; acc += d * d; }
-          out[ob + l] = o[u];
+          if (out) out[ob + l] = o[u];
         }
       }
     }
+    if (FUSE_GRAD) {      // each lane owns its rows of sg: coordinates in, gradient out
+#pragma unroll
+      for (int u = 0; u < ILP; ++u) {
+        const int l = tid + (j0 + u) * TPB;
+        sg[l * 3] = ggx[u] * t[u].mx; sg[l * 3 + 1] = ggy[u] * t[u].my; sg[l * 3 + 2] = ggz[u] * t[u].mz;
+      }
+    }
+  }
+  if (FUSE_GRAD) {
+    __syncthreads();
+    unstage_rows(dgrid + ((long long)n * ovox + vb) * 3, cnt, sg, tid);
   }
   if (FUSE_MSE) {
     __shared__ double red[TPB / kWave];
@@ -649,6 +686,47 @@ KMH_API int kmh_warp_mse_fwd(const float* x, const float* grid, const float* fix
   }
   finalize_mean_kernel<<<1, TPB, 0, s>>>((const double*)ws, (int)(g.x * g.y),
                                          1.0 / ((double)N * C * (double)ovox), out_loss);
+  return KMH_LAUNCH_CHECK();
+}
+
+namespace {
+// dgrid *= g[0] unless g[0] == 1 (the usual loss.backward()): the fused pass already wrote d(loss)/d(grid)
+__global__ __launch_bounds__(TPB) void scale_unless_one_kernel(float* __restrict__ a, long long n4,
+                                                                const float* __restrict__ g) {
+  const float s = g[0];
+  if (s == 1.f) return;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) {
+    float4 v = reinterpret_cast<float4*>(a)[i];
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    reinterpret_cast<float4*>(a)[i] = v;
+  }
+}
+}  // namespace
+
+/* Fused align_img + MSELoss + their backward with respect to the grid, for a loss that IS the mean squared error
+ * (keymorph/utils.py:14-21, loss_ops.py:9-13 and autograd of both; caller scripts/train.py:146-176): one pass writes
+ * out (or nothing when out == NULL), out_loss[0] and dgrid = d(out_loss)/d(grid).  Returns KMH_EINVAL (-22) when the
+ * lane-contiguous kernel does not apply to the shape: the caller then uses the separate entry points. */
+KMH_API int kmh_warp_mse_fwd_grad(const float* x, const float* grid, const float* fixed, float* out, float* out_loss,
+                                  float* dgrid, int N, int C, int D, int H, int W, int Do, int Ho, int Wo, void* ws,
+                                  void* stream) {
+  const long long ovox = (long long)Do * Ho * Wo;
+  dim3 g(ceil_div(ovox, (long long)TPB * VPT), N);
+  if ((long long)g.x * g.y > 65536 * 3 || !lane_contiguous_ok(D, H, W)) return -22;
+  hipStream_t s = (hipStream_t)stream;
+  const double cnt = (double)N * C * (double)ovox;
+  sample_fwd_lc_kernel<0, true, true><<<g, TPB, 0, s>>>(x, grid, out, fixed, (double*)ws, C, D, H, W, ovox, dgrid,
+                                                        (float)(2.0 / cnt));
+  finalize_mean_kernel<<<1, TPB, 0, s>>>((const double*)ws, (int)(g.x * g.y), 1.0 / cnt, out_loss);
+  return KMH_LAUNCH_CHECK();
+}
+
+/* a (n floats, n % 4 == 0, 16-byte aligned) *= g[0], skipped on the device when g[0] == 1 */
+KMH_API int kmh_scale_unless_one(float* a, long long n, const float* g, void* stream) {
+  if (n & 3) return -22;
+  long long nb = (n / 4 + TPB - 1) / TPB;
+  if (nb > 2048) nb = 2048;
+  scale_unless_one_kernel<<<(int)nb, TPB, 0, (hipStream_t)stream>>>(a, n / 4, g);
   return KMH_LAUNCH_CHECK();
 }
 

@@ -110,7 +110,9 @@ def grid_sample3d(x: Tensor, grid: Tensor, mode: str = "bilinear") -> Tensor:
 
 
 class _WarpMSE(torch.autograd.Function):
-    """Fused align_img + MSELoss (one pass; the warped volume is still returned)."""
+    """Fused align_img + MSELoss (one pass; the warped volume is still returned).  When the grid needs a gradient the
+    same pass also writes d(loss)/d(grid) -- the MSE cotangent is known inside the warp -- so the backward is a no-op
+    for the default cotangent 1 (a device-side check) instead of an MSE-backward pass plus a grid-backward pass."""
 
     @staticmethod
     def forward(ctx, x, grid, fixed):
@@ -121,17 +123,34 @@ class _WarpMSE(torch.autograd.Function):
         out = torch.empty((N, C, Do, Ho, Wo), dtype=torch.float32, device=x.device)
         assert fixed.shape == out.shape
         loss = torch.empty((), dtype=torch.float32, device=x.device)
-        if _lib.profiler.enabled:  # grid 12 B + C*(volume 4 + fixed 4 + out 4) B per output voxel
-            _lib.profiler.meta = {"bytes": float(N * Do * Ho * Wo) * (12 + 12 * C)}
-        check(lib.kmh_warp_mse_fwd(_p(x), _p(grid), _p(fixed), _p(out), _p(loss), N, C, D, H, W, Do, Ho, Wo,
-                                   _p(_reduce_ws(x.device)), _stream()), "kmh_warp_mse_fwd")
-        ctx.save_for_backward(x, grid, fixed, out)
+        ctx.dgrid = None
+        if ctx.needs_input_grad[1] and (grid.numel() & 3) == 0:
+            dgrid = torch.empty_like(grid)
+            if _lib.profiler.enabled:  # grid 12 + dgrid 12 + C * (volume 4 + fixed 4 + out 4) B per output voxel
+                _lib.profiler.meta = {"bytes": float(N * Do * Ho * Wo) * (24 + 12 * C)}
+            rc = lib.kmh_warp_mse_fwd_grad(_p(x), _p(grid), _p(fixed), _p(out), _p(loss), _p(dgrid), N, C, D, H, W, Do,
+                                           Ho, Wo, _p(_reduce_ws(x.device)), _stream())
+            if rc == 0:
+                ctx.dgrid = dgrid
+            elif rc != -22:
+                check(rc, "kmh_warp_mse_fwd_grad")
+        if ctx.dgrid is None:
+            if _lib.profiler.enabled:  # grid 12 B + C*(volume 4 + fixed 4 + out 4) B per output voxel
+                _lib.profiler.meta = {"bytes": float(N * Do * Ho * Wo) * (12 + 12 * C)}
+            check(lib.kmh_warp_mse_fwd(_p(x), _p(grid), _p(fixed), _p(out), _p(loss), N, C, D, H, W, Do, Ho, Wo,
+                                       _p(_reduce_ws(x.device)), _stream()), "kmh_warp_mse_fwd")
+            ctx.save_for_backward(x, grid, fixed, out)
         ctx.mark_non_differentiable(out)
         return loss, out
 
     @staticmethod
     def backward(ctx, gloss, _gout):
         lib = _lib.load()
+        if ctx.dgrid is not None:
+            dgrid, ctx.dgrid = ctx.dgrid, None
+            gl = _prep(gloss).reshape(1)
+            check(lib.kmh_scale_unless_one(_p(dgrid), dgrid.numel(), _p(gl), _stream()), "kmh_scale_unless_one")
+            return None, dgrid, None
         x, grid, fixed, out = ctx.saved_tensors
         N, C, D, H, W = x.shape
         _, Do, Ho, Wo, _ = grid.shape

@@ -107,6 +107,31 @@ def test_mse_and_fused_warp_mse():
     close(gh.grad, gr.grad, 1e-8, 2e-4)
 
 
+@pytest.mark.parametrize("shape,scale", [((2, 1, 16, 12, 20), 1.0), ((1, 3, 8, 24, 16), 2.5), ((2, 1, 17, 13, 11), 1.0)])
+def test_warp_mse_single_pass_gradient(shape, scale):
+    """warp + MSE + d(loss)/d(grid) in ONE launch (kmh_warp_mse_fwd_grad; the third shape has no 16-byte-aligned grid
+    and takes the three-launch route): loss, warped volume and grid gradient vs autograd of the oracle, also under a
+    non-unit upstream cotangent (the device-side conditional rescale)."""
+    g = gen(16)
+    n, c, d, h, w = shape
+    a, b = torch.rand(shape, generator=g), torch.rand(shape, generator=g)
+    grid = torch.rand(n, d, h, w, 3, generator=g) * 2.4 - 1.2          # includes out-of-range coordinates (border clamp)
+    gh = grid.to(DEV).requires_grad_(True)
+    lf, warped = ops().warp_mse(a.to(DEV), gh, b.to(DEV))
+    (lf * scale).backward()
+    gr = grid.clone().requires_grad_(True)
+    wr = O.align_img(gr, a)
+    lref = O.mse_loss(b, wr)
+    (lref * scale).backward()
+    close(lf, lref, 1e-7)
+    close(warped, wr, 1e-6)
+    close(gh.grad, gr.grad, 1e-8, 2e-4)
+    with torch.no_grad():                                              # no gradient requested: plain fused forward
+        l2, w2 = ops().warp_mse(a.to(DEV), grid.to(DEV), b.to(DEV))
+    close(l2, lref, 1e-7)
+    close(w2, wr, 1e-6)
+
+
 def test_dice_golden_and_grad():
     from keymorph_amd import loss_ops
     o = golden("ops_small.npz")
