@@ -943,20 +943,29 @@ __global__ __launch_bounds__(UP_TPB, 2) void conv3_up2_fwd_kernel(
     if (ch + 1 < nchunk) commit(ch + 1, stage ^ 1);    // the other stage: its readers finished a chunk ago
     __syncthreads();
   }
-  if (co >= Cout) return;
+  // epilogue: one channel per lane in the accumulators -> 16 bytes per lane after a per-wave transposition through the
+  // (now idle) fragment images: 32 store instructions per lane instead of 128 (the store path is issue-bound, see
+  // conv3_fwd_g_kernel).  Cout % 4 == 0 is guaranteed by the caller (upcat_conv_ok: channels % 8 == 0).
   const int D = 2 * Dl, H = 2 * Hl, W = 2 * Wl;
   const int gz = 2 * zl + pz;
+  float* tile = reinterpret_cast<float*>(&sIn[0][0][0]) + wv * (32 * 32);
+  const int c4 = lane & 7, vx = lane >> 3;
+  const int cq = cog * 64 + 32 * nt + 4 * c4;
+  const bool cq_ok = cq < Cout;
 #pragma unroll
   for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
     for (int m = 0; m < UY; ++m) {
-      if (y0 + m >= Hl) continue;
-      const int gy = 2 * (y0 + m) + py;
-      float* yp = y + ((((long long)n * D + gz) * H + gy) * W) * Cout + co;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int xlw = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (xlw < Wl) yp[(long long)(2 * xlw + pl) * Cout] = acc[pl][m][r] * desc;
+      for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[pl][m][r] * desc;
+      const bool row_ok = cq_ok && y0 + m < Hl;
+      const int gy = 2 * (y0 + m) + py;
+      float* yp = y + ((((long long)n * D + gz) * H + gy) * W) * Cout + cq;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int xx = vx + 8 * k, xlw = x0 + xx;
+        const float4 v = *reinterpret_cast<const float4*>(tile + xx * 32 + 4 * c4);
+        if (row_ok && xlw < Wl) *reinterpret_cast<float4*>(yp + (long long)(2 * xlw + pl) * Cout) = v;
       }
     }
 }
