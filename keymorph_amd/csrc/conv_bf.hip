@@ -440,7 +440,7 @@ __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
     const bf16x8* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int D, int H, int W, int Cin,
     int Cout, int CoutP, int relu_in, int relu_out, int tiles_x, int tiles_y, int tiles_z, int tiles_zp,
     const float* __restrict__ ascale, const float* __restrict__ wscale, double* __restrict__ stats_partial,
-    int in_blocked, const float* __restrict__ addend, int total_items, long long* __restrict__ trace) {
+    int in_blocked, const float* __restrict__ addend, int total_items, int N, long long* __restrict__ trace) {
   constexpr int TERMS = 2, MR = ZP ? 2 : 4;
   constexpr int NST = ZP ? NSTEP_Z : NSTEP;
   static_assert(!ZP || NT == 1, "z-paired tiles are for Cout <= 16");
@@ -451,15 +451,19 @@ __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform by construction: keep it (and wz, wy, the
   const int li = lane & 31, lh = lane >> 5;                    // DMA's LDS bases, the per-wave step tests) in SGPRs
-  const int n = blockIdx.z;
   const int ncog = ZP ? 1 : (Cout + 32 * NT - 1) / (32 * NT);
   const int tyz = (tiles_y + 7) >> 3;
-  // work list of this workgroup: virtual block ids blockIdx.x, + gridDim.x, ... of a launch with `total_items` blocks,
-  // mapped like conv3_fwd_bf_kernel maps its blocks (cout groups adjacent, 8 x 8 (y, z) brick patches per XCD;
-  // gridDim.x is a multiple of 8, so every id of the list lands on this workgroup's XCD)
-  struct Item { int cog, bx, by, bz; };
+  // work list of this workgroup: virtual block ids blockIdx.x, + gridDim.x, ... of a launch with N * total_items
+  // blocks (sample-major), mapped like conv3_fwd_bf_kernel maps its blocks (cout groups adjacent, 8 x 8 (y, z) brick
+  // patches per XCD; gridDim.x is a multiple of 8, so every id of the list lands on this workgroup's XCD).  The
+  // workgroups of an XCD thus work on ~32 consecutive bricks of ONE sample at a time and share their halos through its
+  // L2 (per-sample work lists, 8 consecutive bricks per XCD and sample, fetched 32 % more: PMC r2f vs r2c).
+  struct Item { int n, cog, bx, by, bz; };
+  const int total_all = N * total_items;
   auto decode = [&](int vb, Item& it) -> bool {
-    const int item = xcd_remap(vb, total_items);
+    const int gitem = xcd_remap(vb, total_all);
+    it.n = gitem / total_items;
+    const int item = gitem - it.n * total_items;
     it.cog = item % ncog;
     const int brick = item / ncog;
     const int lz8 = brick & 7, ly8 = (brick >> 3) & 7, patch = brick >> 6;
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
     return it.by < tiles_y && it.bz < tiles_z;             // patches are padded to 8 x 8
   };
   auto next_item = [&](int& vb, Item& it) -> bool {        // advance to the next real brick of the list
-    for (vb += gridDim.x; vb < total_items; vb += gridDim.x)
+    for (vb += gridDim.x; vb < total_all; vb += gridDim.x)
       if (decode(vb, it)) return true;
     return false;
   };
@@ -484,8 +488,8 @@ __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
   const int nchunk = Cin / KC;
   const int vrow = (wz * GHY + wy) * HX + li;
   const long long vox = (long long)D * H * W;
-  const float* xb = in_blocked ? x + (long long)n * nchunk * vox * KC : x + (long long)n * vox * Cin;
   const long long chunk_stride = in_blocked ? vox * KC : KC;
+  auto sample_base = [&](int n) { return in_blocked ? x + (long long)n * nchunk * vox * KC : x + (long long)n * vox * Cin; };
 
   // LDS-DMA descriptors of a brick: 16-byte slot e = r * 512 + tid holds half (e & 1) of halo voxel e >> 1; padding
   // voxels fetch the clamped in-volume voxel (any valid address: the conversion writes zeros for them)
@@ -519,8 +523,8 @@ __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
     }
     return bits;
   };
-  auto dma_chunk = [&](int ch) {                    // this wave's 8 KB of a chunk's halo (offsets of the brick in sOff)
-    const float* base = xb + ch * chunk_stride;
+  auto dma_chunk = [&](int n, int ch) {             // this wave's 8 KB of a chunk's halo (offsets of the brick in sOff)
+    const float* base = sample_base(n) + ch * chunk_stride;
 #pragma unroll
     for (int r = 0; r < G_NLD; ++r) {
       if (r * G_TPB + tid < G_SLOTS)
@@ -561,16 +565,17 @@ __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
   // barrier (cycle stamps, KMH_G_TRACE); MI355X_MICROARCH.md "Two waves per SIMD", item 4
   if (wv >= 4) __builtin_amdgcn_s_setprio(1);
   fill_offsets(cur);
-  dma_chunk(0);
+  dma_chunk(cur.n, 0);
   unsigned cv_in = inside_bits(cur);
   int tr_n = 0;                                            // KMH_G_TRACE: s_memtime stamps of workgroup 0, wave 0
   auto stamp = [&]() {
-    if (trace && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0 && tr_n < 240) trace[tr_n++] = __builtin_readcyclecounter();
+    if (trace && blockIdx.x == 0 && tid == 0 && tr_n < 240) trace[tr_n++] = __builtin_readcyclecounter();
   };
   for (;;) {
     stamp();                                               // brick start
     const bool more = next_item(vb, nxt);
     const int co0 = cur.cog * (32 * NT);
+    const int n = cur.n;
     const int boff = lh * CoutP + co0 + li;
     f32x16 acc[MR][NT];
 #pragma unroll
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
       // MFMAs ahead of its first use -- stays.)
 #pragma unroll
       for (int s = 0; s < NST; ++s) {
-        if (s < 8 && s == wv && have_next) dma_chunk(last_ch ? 0 : ch + 1);
+        if (s < 8 && s == wv && have_next) dma_chunk(last_ch ? nxt.n : n, last_ch ? 0 : ch + 1);
         {   // this step's B fragments: leave only the B loads issued after them in flight
           const int ahead = (s + BD - 1 < NST - 1 ? s + BD - 1 : NST - 1) - s;      // steps already issued beyond s
           switch (ahead * BL) {
@@ -1419,19 +1424,19 @@ static int launch_fwd_g(const float* x, const float* scale, const float* shift, 
   const int tx = ceil_div(W, TX), ty = ceil_div(H, GTY), tz = ceil_div(D, GTZ);
   const int typ = ceil_div(ty, 8), tzp = ceil_div(tz, 8);
   const int total = tx * typ * tzp * 64 * (ZP ? 1 : ceil_div(Cout, 32 * NT));      // virtual blocks per sample
-  // persistent workgroups, one per CU: the 256 CUs are shared out over the samples in multiples of 8 (so that every id
-  // of a workgroup's list falls on its own XCD)
-  int wgs = ((256 / (N < 32 ? N : 32)) / 8) * 8;
-  if (wgs < 8) wgs = 8;
-  if (wgs > ((total + 7) / 8) * 8) wgs = ((total + 7) / 8) * 8;
-  dim3 g(wgs, 1, N);
+  // persistent workgroups, one per CU, over ONE work list of N * total bricks (a multiple of 8 workgroups, so that every
+  // id of a workgroup's list falls on its own XCD)
+  long long all = (long long)N * total;
+  int wgs = 256;
+  if (wgs > ((all + 7) / 8) * 8) wgs = (int)(((all + 7) / 8) * 8);
+  dim3 g(wgs, 1, 1);
   static long long* trace = nullptr;                       // KMH_G_TRACE=1 (debug): cycle stamps of workgroup 0 to stderr
   static const bool tracing = getenv("KMH_G_TRACE") != nullptr;
   if (tracing && !trace) { if (hipMalloc(&trace, 240 * sizeof(long long)) != hipSuccess) trace = nullptr; }
   if (tracing && trace) (void)hipMemsetAsync(trace, 0, 240 * sizeof(long long), s);
   conv3_fwd_g_kernel<NT, ZP><<<g, G_TPB, G_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in,
                                                            relu_out, tx, ty, tz, tzp, ascale, wscale,
-                                                           stats_out ? stats_ws : nullptr, in_blocked, addend, total,
+                                                           stats_out ? stats_ws : nullptr, in_blocked, addend, total, N,
                                                            tracing ? trace : nullptr);
   if (tracing && trace) {
     long long h[240];
