@@ -400,17 +400,51 @@ __global__ __launch_bounds__(256) void headcom_pack_bf_kernel(const float* __res
 }
 
 // feature tile (VTT voxels x 64 ci, fp32 NDHWC) -> sF[t][voxel][ci] and optionally sFT[t][ci][sigma(voxel)]; coords
+// Two halves so that a kernel can keep the NEXT tile's loads in flight under the current tile's MFMAs:
+//   FeatRegs r; feat_fetch(r, tile + 1);  ... compute tile ...  barrier; feat_commit(r)
+template <int VTT, int NTHR>
+struct FeatRegs {
+  static constexpr int ITEMS = (VTT / 2) * 16;         // (voxel pair, 4-channel quad)
+  static constexpr int NIT = (ITEMS + NTHR - 1) / NTHR;
+  float4 x0[NIT], x1[NIT];
+};
+template <int VTT, int NTHR>
+__device__ __forceinline__ void feat_fetch(FeatRegs<VTT, NTHR>& r, const float* __restrict__ feat, long long v0,
+                                           long long V, int Cin, int tid) {
+#pragma unroll
+  for (int k = 0; k < FeatRegs<VTT, NTHR>::NIT; ++k) {
+    const int e = tid + k * NTHR;
+    const int c4 = e & 15, v = 2 * (e >> 4);
+    r.x0[k] = r.x1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < FeatRegs<VTT, NTHR>::ITEMS && 4 * c4 < Cin) {
+      if (v0 + v < V) r.x0[k] = *reinterpret_cast<const float4*>(feat + (v0 + v) * Cin + 4 * c4);
+      if (v0 + v + 1 < V) r.x1[k] = *reinterpret_cast<const float4*>(feat + (v0 + v + 1) * Cin + 4 * c4);
+    }
+  }
+}
+template <int TERMS, int VTT, int NTHR, bool TRANSPOSED>
+__device__ __forceinline__ void feat_commit(const FeatRegs<VTT, NTHR>& r, long long v0, long long V, Dims d,
+                                            unsigned char* sF, unsigned char* sFT, float4* sC, int tid, float sFs,
+                                            bool coords);
+
 template <int TERMS, int VTT, int NTHR, bool TRANSPOSED>
 __device__ __forceinline__ void stage_feat_bf(const float* __restrict__ feat, long long v0, long long V, int Cin, Dims d,
                                               unsigned char* sF, unsigned char* sFT, float4* sC, int tid, float sFs) {
-  constexpr int ITEMS = (VTT / 2) * 16;                // (voxel pair, 4-channel quad)
-  for (int e = tid; e < ITEMS; e += NTHR) {
+  FeatRegs<VTT, NTHR> r;
+  feat_fetch<VTT, NTHR>(r, feat, v0, V, Cin, tid);
+  feat_commit<TERMS, VTT, NTHR, TRANSPOSED>(r, v0, V, d, sF, sFT, sC, tid, sFs, true);
+}
+
+template <int TERMS, int VTT, int NTHR, bool TRANSPOSED>
+__device__ __forceinline__ void feat_commit(const FeatRegs<VTT, NTHR>& r, long long v0, long long V, Dims d,
+                                            unsigned char* sF, unsigned char* sFT, float4* sC, int tid, float sFs,
+                                            bool coords) {
+#pragma unroll
+  for (int k = 0; k < FeatRegs<VTT, NTHR>::NIT; ++k) {
+    const int e = tid + k * NTHR;
+    if (e >= FeatRegs<VTT, NTHR>::ITEMS) break;
     const int c4 = e & 15, vp = e >> 4, v = 2 * vp;
-    float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-    if (4 * c4 < Cin) {
-      if (v0 + v < V) x0 = *reinterpret_cast<const float4*>(feat + (v0 + v) * Cin + 4 * c4);
-      if (v0 + v + 1 < V) x1 = *reinterpret_cast<const float4*>(feat + (v0 + v + 1) * Cin + 4 * c4);
-    }
+    float4 x0 = r.x0[k], x1 = r.x1[k];
     x0.x *= sFs; x0.y *= sFs; x0.z *= sFs; x0.w *= sFs;          // power-of-two range scale (1 for TERMS == 3)
     x1.x *= sFs; x1.y *= sFs; x1.z *= sFs; x1.w *= sFs;
     uint2 s0[TERMS], s1[TERMS];
@@ -435,7 +469,7 @@ __device__ __forceinline__ void stage_feat_bf(const float* __restrict__ feat, lo
       }
     }
   }
-  if (tid < VTT) {
+  if (coords && tid < VTT) {
     const long long v = v0 + tid;
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
     if (v < V) {
@@ -449,6 +483,23 @@ __device__ __forceinline__ void stage_feat_bf(const float* __restrict__ feat, lo
   }
 }
 
+// ROWS kernels walk 32-voxel blocks of whole x rows in order: the block's (x, y, z) origin is advanced with three
+// compares instead of being re-derived with 64-bit divisions (~125 scalar instructions each) for every block.
+struct RowCursor {
+  int x, y, z;
+  __device__ __forceinline__ void set(long long v, Dims d) {
+    const unsigned u = (unsigned)v;                     // ROWS launches guarantee V < 2^31
+    const unsigned row = u / (unsigned)d.W;
+    x = (int)(u - row * (unsigned)d.W);
+    z = (int)(row / (unsigned)d.H);
+    y = (int)(row - (unsigned)z * (unsigned)d.H);
+  }
+  __device__ __forceinline__ void advance32(Dims d) {   // the next 32-voxel block of the same sample (wraps to 0,0,0)
+    x += 32;
+    if (x >= d.W) { x = 0; if (++y >= d.H) { y = 0; if (++z >= d.D) z = 0; } }
+  }
+};
+
 constexpr int FVT = 128;   // forward: voxels per tile
 constexpr int WVT = 64;    // dW kernel: voxels per tile (its transposed image has 64 columns)
 
@@ -457,20 +508,24 @@ constexpr int WVT = 64;    // dW kernel: voxels per tile (its transposed image h
 // moment sums need the voxel coordinates only once per block (z, y) or as compile-time offsets (x): 4 VALU per logit
 // instead of 9 and no coordinate reads.  (The epilogue, not the MFMAs, bounds this kernel: 16 logits per lane per
 // 12 MFMAs.)  Coordinates are accumulated as voxel INDICES and scaled by 1/(dim-1) when the partials are written.
-template <int TERMS, bool ROWS>
-__global__ __launch_bounds__(HTPB, 3) void headcom_fwd_bf_kernel(const float* __restrict__ feat,
+// NWV waves per workgroup = 32 NWV keypoint channels share one staged (converted) feature tile: 4 (128 channels, 3
+// workgroups per CU) or 16 (all 512 channels of the headline config on one tile image -- the conversion, which is
+// what bounds these kernels, is then done once per tile instead of once per 128-channel group).
+template <int TERMS, bool ROWS, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 1) void headcom_fwd_bf_kernel(const float* __restrict__ feat,
                                                                  const __bf16* __restrict__ wk,
                                                                  const float* __restrict__ bias,
                                                                  double* __restrict__ partial, long long V, int Cin,
                                                                  int Cout, int CoutP, Dims d, int tiles_per_slab,
-                                                                 int nslab, int ngroups, const float* __restrict__ hs) {
+                                                                 int nslab, int ngroups, const float* __restrict__ hs,
+                                                                 int want_sq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
-  unsigned char* sF = hsm;                                            // [TERMS][FVT][128 B]
-  float4* sC = reinterpret_cast<float4*>(hsm + TERMS * FVT * 128);     // [FVT]
+  constexpr int FBUF = TERMS * FVT * 128 + FVT * 16;                   // one buffer: sF [TERMS][FVT][128 B] + sC [FVT]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int item = xcd_remap(blockIdx.x, gridDim.x);                  // channel groups of one slab share an L2
   const int grp = item % ngroups, slab = item / ngroups, n = blockIdx.y;
-  const int co = grp * GC + 32 * wv + li;
+  constexpr int NT_ = 64 * NWV;
+  const int co = grp * (32 * NWV) + 32 * wv + li;
   const int nks = (Cin + 15) >> 4;
   const float* fn = feat + (long long)n * V * Cin;
   bf16x8 bw[4][TERMS];
@@ -486,15 +541,31 @@ __global__ __launch_bounds__(HTPB, 3) void headcom_fwd_bf_kernel(const float* __
   long long t_beg = (long long)slab * tiles_per_slab, t_end = t_beg + tiles_per_slab;
   if (t_end > ntiles) t_end = ntiles;
   const float bv_s = bv / desc;               // ROWS: the accumulator starts at bias / descale, h' = max(acc, 0) = h / descale
+  f32x16 acc0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = ROWS ? bv_s : 0.f;
+  // Two LDS buffers, one barrier per tile: a wave converts tile t+1 (fetched under tile t's MFMAs) into the other
+  // buffer as soon as ITS tile-t blocks are done, while slower waves are still on the matrix cores.
+  FeatRegs<FVT, NT_> pre;
+  auto commit = [&](long long tile) {
+    unsigned char* b = hsm + (int)((tile - t_beg) & 1) * FBUF;
+    feat_commit<TERMS, FVT, NT_, false>(pre, tile * FVT, V, d, b, nullptr, reinterpret_cast<float4*>(b + TERMS * FVT * 128),
+                                        tid, sFs, !ROWS);
+  };
+  if (t_beg < t_end) {
+    feat_fetch<FVT, NT_>(pre, fn, t_beg * FVT, V, Cin, tid);
+    commit(t_beg);
+    if (t_beg + 1 < t_end) feat_fetch<FVT, NT_>(pre, fn, (t_beg + 1) * FVT, V, Cin, tid);
+  }
+  __syncthreads();
+  RowCursor cur;
+  if (ROWS) cur.set(t_beg * FVT, d);
   for (long long tile = t_beg; tile < t_end; ++tile) {
-    __syncthreads();
-    stage_feat_bf<TERMS, FVT, HTPB, false>(fn, tile * FVT, V, Cin, d, sF, nullptr, sC, tid, sFs);
-    __syncthreads();
+    const unsigned char* sF = hsm + (int)((tile - t_beg) & 1) * FBUF;
+    const float4* sC = reinterpret_cast<const float4*>(sF + TERMS * FVT * 128);
 #pragma unroll 1
     for (int vb = 0; vb < FVT / 32; ++vb) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = ROWS ? bv_s : 0.f;
+      f32x16 acc = acc0;                     // the first product reads acc0 as its C operand: no per-block initialisation
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if (s < nks) {
@@ -506,15 +577,24 @@ __global__ __launch_bounds__(HTPB, 3) void headcom_fwd_bf_kernel(const float* __
         }
       }
       if (ROWS) {
-        const long long vfirst = tile * FVT + 32 * vb;                 // wave-uniform
-        const int xb = (int)(vfirst % d.W), yb = (int)((vfirst / d.W) % d.H), zb = (int)(vfirst / ((long long)d.W * d.H));
+        const int xb = cur.x, yb = cur.y, zb = cur.z;                  // wave-uniform origin of block tile * FVT + 32 vb
+        cur.advance32(d);
         float R = 0.f, T = 0.f;
+        if (want_sq) {                       // sum relu(h)^2: keypoint weighting at inference only (head_moments)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float h = fmaxf(acc[r], 0.f);
-          R += h;
-          T = fmaf(h, (float)((r & 3) + 8 * (r >> 2)), T);
-          S[4] = fmaf(h, h, S[4]);
+          for (int r = 0; r < 16; ++r) {
+            const float h = fmaxf(acc[r], 0.f);
+            R += h;
+            T = fmaf(h, (float)((r & 3) + 8 * (r >> 2)), T);
+            S[4] = fmaf(h, h, S[4]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float h = fmaxf(acc[r], 0.f);
+            R += h;
+            T = fmaf(h, (float)((r & 3) + 8 * (r >> 2)), T);
+          }
         }
         S[0] += R;
         S[1] = fmaf(R, (float)zb, S[1]);
@@ -529,6 +609,11 @@ __global__ __launch_bounds__(HTPB, 3) void headcom_fwd_bf_kernel(const float* __
         S[0] += h; S[1] += h * c.x; S[2] += h * c.y; S[3] += h * c.z; S[4] += h * h;
       }
     }
+    if (tile + 1 < t_end) {
+      commit(tile + 1);
+      if (tile + 2 < t_end) feat_fetch<FVT, NT_>(pre, fn, (tile + 2) * FVT, V, Cin, tid);
+    }
+    __syncthreads();
   }
   if (ROWS) {   // back to descaled logits and normalised coordinates
     S[0] *= desc; S[4] *= desc * desc;
@@ -547,8 +632,8 @@ __global__ __launch_bounds__(HTPB, 3) void headcom_fwd_bf_kernel(const float* __
 // ---- dW / db: workgroup = (slab of 64-voxel tiles over all samples, 128 channels); wave = 32 channels -----
 // ROWS (W % 32 == 0, V % WVT == 0): as in the forward kernel -- the accumulator starts at bias / descale, the gradient
 // coefficients carry the operand's range scale, and the per-voxel factor is one fma on the block's row constants.
-template <int TERMS, bool ROWS>
-__global__ __launch_bounds__(HTPB, 2) void headcom_bwd_w_bf_kernel(const float* __restrict__ feat,
+template <int TERMS, bool ROWS, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void headcom_bwd_w_bf_kernel(const float* __restrict__ feat,
                                                                    const __bf16* __restrict__ wk,
                                                                    const float* __restrict__ bias,
                                                                    const float* __restrict__ g,
@@ -558,13 +643,13 @@ __global__ __launch_bounds__(HTPB, 2) void headcom_bwd_w_bf_kernel(const float* 
                                                                    int tiles_per_slab, int ngroups,
                                                                    const float* __restrict__ hs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
-  unsigned char* sF = hsm;                                    // [TERMS][64 voxels][128 B]
-  unsigned char* sFT = hsm + TERMS * WVT * 128;               // [TERMS][64 ci][128 B]  (columns = sigma(voxel))
-  float4* sC = reinterpret_cast<float4*>(hsm + 2 * TERMS * WVT * 128);
+  // one buffer: sF [TERMS][64 voxels][128 B] + sFT [TERMS][64 ci][128 B] (columns = sigma(voxel)) + sC [64]
+  constexpr int WBUF = 2 * TERMS * WVT * 128 + WVT * 16;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int item = xcd_remap(blockIdx.x, gridDim.x);
   const int grp = item % ngroups, slab = item / ngroups;
-  const int co = grp * GC + 32 * wv + li;
+  constexpr int NT_ = 64 * NWV;
+  const int co = grp * (32 * NWV) + 32 * wv + li;
   const int nks = (Cin + 15) >> 4;
   bf16x8 bw[4][TERMS];
 #pragma unroll
@@ -580,22 +665,44 @@ __global__ __launch_bounds__(HTPB, 2) void headcom_bwd_w_bf_kernel(const float* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) dw[ct][r] = 0.f;
   float db = 0.f;
+  f32x16 acc0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = ROWS ? bv / desc : 0.f;
   const long long tiles_per_n = (V + WVT - 1) / WVT, ntiles = tiles_per_n * N;
   long long t_beg = (long long)slab * tiles_per_slab, t_end = t_beg + tiles_per_slab;
   if (t_end > ntiles) t_end = ntiles;
+  FeatRegs<WVT, NT_> pre;                    // the next tile's features, in flight under this tile's MFMAs
+  // (sample, first voxel) of the current tile, stepped without divisions: tiles never straddle samples
+  int n = t_beg < t_end ? (int)(t_beg / tiles_per_n) : 0;
+  long long v0 = (t_beg - (long long)n * tiles_per_n) * WVT;
+  // Two LDS buffers, one barrier per tile (see the forward kernel): tile t+1 is converted into the other buffer by each
+  // wave right after its own tile-t blocks; tile t+2 is then fetched.
+  auto commit = [&](long long tile, long long vfirst) {
+    unsigned char* b = hsm + (int)((tile - t_beg) & 1) * WBUF;
+    feat_commit<TERMS, WVT, NT_, true>(pre, vfirst, V, d, b, b + TERMS * WVT * 128,
+                                       reinterpret_cast<float4*>(b + 2 * TERMS * WVT * 128), tid, sFs, !ROWS);
+  };
+  auto step = [&](int& nn, long long& vv) { vv += WVT; if (vv >= V) { vv = 0; ++nn; } };
+  int n_next = n;                            // (sample, first voxel) of the tile after the current one
+  long long v_next = v0;
+  step(n_next, v_next);
+  if (t_beg < t_end) {
+    feat_fetch<WVT, NT_>(pre, feat + (long long)n * V * Cin, v0, V, Cin, tid);
+    commit(t_beg, v0);
+    if (t_beg + 1 < t_end) feat_fetch<WVT, NT_>(pre, feat + (long long)n_next * V * Cin, v_next, V, Cin, tid);
+  }
+  __syncthreads();
+  RowCursor cur;
+  if (ROWS) cur.set(v0, d);
   for (long long tile = t_beg; tile < t_end; ++tile) {
-    const int n = (int)(tile / tiles_per_n);
-    const long long v0 = (tile - (long long)n * tiles_per_n) * WVT;
-    __syncthreads();
-    stage_feat_bf<TERMS, WVT, HTPB, true>(feat + (long long)n * V * Cin, v0, V, Cin, d, sF, sFT, sC, tid, sFs);
+    const unsigned char* sF = hsm + (int)((tile - t_beg) & 1) * WBUF;
+    const unsigned char* sFT = sF + TERMS * WVT * 128;
+    const float4* sC = reinterpret_cast<const float4*>(sF + 2 * TERMS * WVT * 128);
     const float4 gv = co < Cout ? *reinterpret_cast<const float4*>(g + ((long long)n * Cout + co) * 4)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
 #pragma unroll 1
     for (int vb = 0; vb < WVT / 32; ++vb) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = ROWS ? bv / desc : 0.f;
+      f32x16 acc = acc0;                     // the first product reads acc0 as its C operand
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if (s < nks) {
@@ -609,8 +716,8 @@ __global__ __launch_bounds__(HTPB, 2) void headcom_bwd_w_bf_kernel(const float* 
       // dh = [h > 0] (g0 + gz cz + gy cy + gx cx): lane = channel, register r = voxel row
       float dh[16];
       if (ROWS) {
-        const long long vfirst = v0 + 32 * vb;                         // wave-uniform
-        const int xb = (int)(vfirst % d.W), yb = (int)((vfirst / d.W) % d.H), zb = (int)(vfirst / ((long long)d.W * d.H));
+        const int xb = cur.x, yb = cur.y, zb = cur.z;                  // wave-uniform origin of block v0 + 32 vb
+        cur.advance32(d);                                              // (wraps to the origin at a sample boundary)
         const float iz = d.D > 1 ? 1.f / (float)(d.D - 1) : 0.f, iy = d.H > 1 ? 1.f / (float)(d.H - 1) : 0.f,
                     ix = d.W > 1 ? 1.f / (float)(d.W - 1) : 0.f;
         const float gxs = gv.w * ix * sDh;                             // per x step, in the operand's range scale
@@ -637,14 +744,24 @@ __global__ __launch_bounds__(HTPB, 2) void headcom_bwd_w_bf_kernel(const float* 
         split8<TERMS>(dh + 8 * s2, a);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-          bf16x8 b[TERMS];
+          if (32 * ct < Cin) {                           // wave-uniform: no products against the zero padding of Cin <= 32
+            bf16x8 b[TERMS];
 #pragma unroll
-          for (int t = 0; t < TERMS; ++t)
-            b[t] = *reinterpret_cast<const bf16x8*>(sFT + t * (64 * 128) + swz(32 * ct + li, 4 * vb + 2 * s2 + lh));
-          dw[ct] = mfma_split<TERMS>(a, b, dw[ct]);
+            for (int t = 0; t < TERMS; ++t)
+              b[t] = *reinterpret_cast<const bf16x8*>(sFT + t * (64 * 128) + swz(32 * ct + li, 4 * vb + 2 * s2 + lh));
+            dw[ct] = mfma_split<TERMS>(a, b, dw[ct]);
+          }
         }
       }
     }
+    n = n_next;
+    v0 = v_next;
+    step(n_next, v_next);
+    if (tile + 1 < t_end) {
+      commit(tile + 1, v0);
+      if (tile + 2 < t_end) feat_fetch<WVT, NT_>(pre, feat + (long long)n_next * V * Cin, v_next, V, Cin, tid);
+    }
+    __syncthreads();
   }
   float* ow = pw + (long long)slab * Cout * Cin;
 #pragma unroll
@@ -652,7 +769,7 @@ __global__ __launch_bounds__(HTPB, 2) void headcom_bwd_w_bf_kernel(const float* 
     const int c = 32 * ct + li;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int k = grp * GC + 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int k = grp * (32 * NWV) + 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (k < Cout && c < Cin) ow[(long long)k * Cin + c] = dw[ct][r] * desc_w;
     }
   }
@@ -794,11 +911,13 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_bf_kernel(const fl
         split8<TERMS>(dh + 8 * s2, b);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          bf16x8 a[TERMS];
+          if (32 * mt < Cin) {                           // wave-uniform: rows ci >= Cin of W^T are zero padding
+            bf16x8 a[TERMS];
 #pragma unroll
-          for (int t = 0; t < TERMS; ++t)
-            a[t] = *reinterpret_cast<const bf16x8*>(sWt + t * (64 * 128) + swz(32 * mt + li, 4 * m + 2 * s2 + lh));
-          acc2[mt] = mfma_split<TERMS>(a, b, acc2[mt]);
+            for (int t = 0; t < TERMS; ++t)
+              a[t] = *reinterpret_cast<const bf16x8*>(sWt + t * (64 * 128) + swz(32 * mt + li, 4 * m + 2 * s2 + lh));
+            acc2[mt] = mfma_split<TERMS>(a, b, acc2[mt]);
+          }
         }
       }
     }
@@ -939,16 +1058,19 @@ static int head_scales(const float* feat, long long nfeat, const float* w, long 
 }
 
 struct HeadBfPlan {
-  int CoutP, ngroups, nslab_f, tps_f, nslab_w, tps_w;
+  int CoutP, nwv, ngroups, nwv_w, ngroups_w, nslab_f, tps_f, nslab_w, tps_w;
   size_t img_bytes;     // the three pre-split weight images
 };
 static HeadBfPlan head_bf_plan(int N, long long V, int Cout, int terms) {
   HeadBfPlan p;
   p.CoutP = ceil_div(Cout, GC) * GC;
-  p.ngroups = p.CoutP / GC;
+  p.nwv = (p.CoutP % 512 == 0) ? 16 : 4;            // waves (32-channel tiles) per workgroup
+  p.ngroups = p.CoutP / (32 * p.nwv);
+  p.nwv_w = (p.CoutP % 256 == 0) ? 8 : 4;           // dW kernel: its accumulators cap it at 8 waves per CU
+  p.ngroups_w = p.CoutP / (32 * p.nwv_w);
   {
     const long long ntiles = (V + FVT - 1) / FVT;
-    long long want = 1536 / ((long long)p.ngroups * (N > 0 ? N : 1));
+    long long want = (p.nwv == 16 ? 256 : 1536) / ((long long)p.ngroups * (N > 0 ? N : 1));
     if (want < 1) want = 1;
     if (want > ntiles) want = ntiles;
     p.tps_f = (int)((ntiles + want - 1) / want);
@@ -956,7 +1078,7 @@ static HeadBfPlan head_bf_plan(int N, long long V, int Cout, int terms) {
   }
   {
     const long long ntiles = ((V + WVT - 1) / WVT) * N;
-    long long want = 1536 / p.ngroups;
+    long long want = (p.nwv_w == 8 ? 512 : 1536) / p.ngroups_w;
     if (want < 1) want = 1;
     if (want > ntiles) want = ntiles;
     p.tps_w = (int)((ntiles + want - 1) / want);
@@ -989,13 +1111,14 @@ static int head_fwd_bf(const float* feat, const float* w, const float* bias, flo
   rc = head_pack<TERMS>(w, Cout, Cin, p, img, hs, s);
   if (rc) return rc;
   Dims d{D, H, W};
-  const size_t lds = (size_t)TERMS * FVT * 128 + FVT * sizeof(float4);
-  const bool rows = W % 32 == 0 && V % FVT == 0;
-  auto kern = rows ? headcom_fwd_bf_kernel<TERMS, true> : headcom_fwd_bf_kernel<TERMS, false>;
+  const size_t lds = 2 * ((size_t)TERMS * FVT * 128 + FVT * sizeof(float4));   // double buffered
+  const bool rows = W % 32 == 0 && V % FVT == 0 && V < (1ll << 31);
+  auto kern = p.nwv == 16 ? (rows ? headcom_fwd_bf_kernel<TERMS, true, 16> : headcom_fwd_bf_kernel<TERMS, false, 16>)
+                          : (rows ? headcom_fwd_bf_kernel<TERMS, true, 4> : headcom_fwd_bf_kernel<TERMS, false, 4>);
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  kern<<<dim3(p.nslab_f * p.ngroups, N), HTPB, lds, s>>>(feat, (const __bf16*)img, bias, partial, V, Cin, Cout, p.CoutP, d,
-                                                         p.tps_f, p.nslab_f, p.ngroups, hs);
+  kern<<<dim3(p.nslab_f * p.ngroups, N), 64 * p.nwv, lds, s>>>(feat, (const __bf16*)img, bias, partial, V, Cin, Cout, p.CoutP, d,
+                                                         p.tps_f, p.nslab_f, p.ngroups, hs, sq != nullptr);
   headcom_final_kernel<<<ceil_div(N * Cout, 64), 64, 0, s>>>(partial, p.nslab_f, N * Cout, pts, sums, sq);
   if (scales_out) head_scales_copy_kernel<<<1, 64, 0, s>>>(hs, scales_out);
   return KMH_LAUNCH_CHECK();
@@ -1036,12 +1159,14 @@ static int head_bwd_bf(const float* dpts, const float* dpower, const float* feat
     if (dfeat_scale2) kmh_absmax::final_kernel<<<1, 1, 0, s>>>(dfeat_scale2, 0.f);
   }
   if (dw) {
-    const size_t lds = (size_t)2 * TERMS * WVT * 128 + WVT * sizeof(float4);
-    auto kern = (W % 32 == 0 && V % WVT == 0) ? headcom_bwd_w_bf_kernel<TERMS, true> : headcom_bwd_w_bf_kernel<TERMS, false>;
+    const size_t lds = 2 * ((size_t)2 * TERMS * WVT * 128 + WVT * sizeof(float4));   // double buffered
+    const bool rows = W % 32 == 0 && V % WVT == 0 && V < (1ll << 31);
+    auto kern = p.nwv_w == 8 ? (rows ? headcom_bwd_w_bf_kernel<TERMS, true, 8> : headcom_bwd_w_bf_kernel<TERMS, false, 8>)
+                             : (rows ? headcom_bwd_w_bf_kernel<TERMS, true, 4> : headcom_bwd_w_bf_kernel<TERMS, false, 4>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    kern<<<dim3(p.nslab_w * p.ngroups), HTPB, lds, s>>>(feat, wk, bias, g, pw, pb, N, V, Cin, Cout, p.CoutP, d, p.tps_w,
-                                                        p.ngroups, hs);
+    kern<<<dim3(p.nslab_w * p.ngroups_w), 64 * p.nwv_w, lds, s>>>(feat, wk, bias, g, pw, pb, N, V, Cin, Cout, p.CoutP, d,
+                                                                  p.tps_w, p.ngroups_w, hs);
     int nb = ceil_div((long long)Cout * Cin, 256);
     if (nb > 1024) nb = 1024;
     headcom_reduce_kernel<<<nb, 256, 0, s>>>(pw, p.nslab_w, (long long)Cout * Cin, dw);
