@@ -367,6 +367,64 @@ __global__ __launch_bounds__(TPB) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
+// 16-byte versions (C % 4 == 0, fewer than 2^31 pooled elements per sample): one thread owns 4 channels of a pooled
+// voxel; a wave reads / writes whole runs of consecutive full-resolution voxels (both x children per thread).  Same
+// first-max rule and the same results as the scalar kernels, a quarter of the memory instructions, 32-bit indices.
+__device__ __forceinline__ void first_max(float v, int k, float& m, int& am) {
+  if (v > m || v != v) { m = v; am = k; }
+}
+__global__ __launch_bounds__(TPB) void maxpool_fwd4_kernel(const float4* __restrict__ x, float4* __restrict__ y,
+                                                           unsigned* __restrict__ arg /* 4 window indices | NULL */, int D,
+                                                           int H, int W, int C4, int Do, int Ho, int Wo) {
+  const int n = blockIdx.y;
+  const int total = Do * Ho * Wo * C4;
+  const float4* xn = x + (long long)n * D * H * W * C4;
+  for (int e = blockIdx.x * TPB + threadIdx.x; e < total; e += gridDim.x * TPB) {
+    const int c = e % C4, v = e / C4;
+    const int xo = v % Wo, r = v / Wo, yo = r % Ho, zo = r / Ho;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int zz = 2 * zo + (k >> 2), yy = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+      const float4 val = xn[((long long)(zz * H + yy) * W + xx) * C4 + c];
+      first_max(val.x, k, m.x, a0); first_max(val.y, k, m.y, a1); first_max(val.z, k, m.z, a2); first_max(val.w, k, m.w, a3);
+    }
+    y[(long long)n * total + e] = m;
+    if (arg) arg[(long long)n * total + e] = (unsigned)a0 | ((unsigned)a1 << 8) | ((unsigned)a2 << 16) | ((unsigned)a3 << 24);
+  }
+}
+
+template <bool BLOCKED>
+__global__ __launch_bounds__(TPB) void maxpool_bwd4_kernel(const unsigned* __restrict__ argm, const float4* __restrict__ dy,
+                                                           const float* add, int acs, float* dx, int D, int H, int W,
+                                                           int C4, int Do, int Ho, int Wo) {
+  const int n = blockIdx.y;
+  const int total = Do * Ho * Wo * C4;
+  const long long V = (long long)D * H * W;
+  float* dxn = dx + (long long)n * V * C4 * 4;
+  const float* an = add ? add + (long long)n * V * acs : nullptr;
+  for (int e = blockIdx.x * TPB + threadIdx.x; e < total; e += gridDim.x * TPB) {
+    const int c = e % C4, v = e / C4;
+    const int xo = v % Wo, r = v / Wo, yo = r % Ho, zo = r / Ho;
+    const unsigned a = argm[(long long)n * total + e];
+    const float4 g = dy[(long long)n * total + e];
+    const int a0 = a & 255, a1 = (a >> 8) & 255, a2 = (a >> 16) & 255, a3 = a >> 24;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int zz = 2 * zo + (k >> 2), yy = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+      const long long vox = (long long)(zz * H + yy) * W + xx;
+      float4 val = make_float4(k == a0 ? g.x : 0.f, k == a1 ? g.y : 0.f, k == a2 ? g.z : 0.f, k == a3 ? g.w : 0.f);
+      if (an) {
+        const float4 s4 = *reinterpret_cast<const float4*>(an + vox * acs + 4 * c);
+        val.x += s4.x; val.y += s4.y; val.z += s4.z; val.w += s4.w;
+      }
+      const long long o = BLOCKED ? ((long long)(c >> 1) * V + vox) * 8 + 4 * (c & 1) : (vox * C4 + c) * 4;
+      *reinterpret_cast<float4*>(dxn + o) = val;     // (non-temporal stores measured 2x slower here)
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // out[n, z,y,x, :] = cat(skip[n,z,y,x,:Cs], low[n, nearest(z,y,x), :Cl])
 __device__ __forceinline__ int nearest_src(int dst, int in_size, int out_size) {
@@ -688,8 +746,12 @@ KMH_API int kmh_relu_mask(const float* dy, const float* y, long long n, float* d
 KMH_API int kmh_maxpool3d_fwd(const float* x, float* y, unsigned char* argmax, int N, int D, int H, int W, int C,
                               void* stream) {
   const int Do = D / 2, Ho = H / 2, Wo = W / 2;
-  maxpool_fwd_kernel<<<dim3(stream_blocks((long long)Do * Ho * Wo * C), N), TPB, 0, (hipStream_t)stream>>>(
-      x, y, argmax, D, H, W, C, Do, Ho, Wo);
+  const long long pooled = (long long)Do * Ho * Wo * C;
+  if ((C & 3) == 0 && pooled / 4 < (1ll << 31) && (long long)D * H * W < (1ll << 31))
+    maxpool_fwd4_kernel<<<dim3(stream_blocks(pooled), N), TPB, 0, (hipStream_t)stream>>>(
+        (const float4*)x, (float4*)y, (unsigned*)argmax, D, H, W, C / 4, Do, Ho, Wo);
+  else
+    maxpool_fwd_kernel<<<dim3(stream_blocks(pooled), N), TPB, 0, (hipStream_t)stream>>>(x, y, argmax, D, H, W, C, Do, Ho, Wo);
   return KMH_LAUNCH_CHECK();
 }
 
@@ -701,8 +763,15 @@ KMH_API int kmh_maxpool3d_bwd(const float* x, const unsigned char* argmax, const
   const int Do = D / 2, Ho = H / 2, Wo = W / 2;
   if ((add && add_cstride < C) || (!x && !argmax)) return -22;
   if (out_blocked && ((C & 7) || (D & 1) || (H & 1) || (W & 1) || add == dx)) return -22;   // whole chunks, every voxel written
-  maxpool_bwd_kernel<<<dim3(stream_blocks((long long)Do * Ho * Wo * C), N), TPB, 0, (hipStream_t)stream>>>(
-      x, argmax, dy, add, add_cstride, dx, D, H, W, C, Do, Ho, Wo, out_blocked);
+  const long long pooled = (long long)Do * Ho * Wo * C;
+  if (argmax && (C & 3) == 0 && (add_cstride & 3) == 0 && pooled / 4 < (1ll << 31) && (long long)D * H * W < (1ll << 31)) {
+    auto kern = out_blocked ? maxpool_bwd4_kernel<true> : maxpool_bwd4_kernel<false>;
+    kern<<<dim3(stream_blocks(pooled), N), TPB, 0, (hipStream_t)stream>>>((const unsigned*)argmax, (const float4*)dy, add,
+                                                                         add_cstride, dx, D, H, W, C / 4, Do, Ho, Wo);
+  } else {
+    maxpool_bwd_kernel<<<dim3(stream_blocks(pooled), N), TPB, 0, (hipStream_t)stream>>>(
+        x, argmax, dy, add, add_cstride, dx, D, H, W, C, Do, Ho, Wo, out_blocked);
+  }
   return KMH_LAUNCH_CHECK();
 }
 
