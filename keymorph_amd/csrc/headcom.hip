@@ -151,6 +151,14 @@ __global__ void headcom_coef_kernel(const float* __restrict__ dpts, const float*
                                     const float* __restrict__ sums, int NK, float* __restrict__ g) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= NK) return;
+  // A dead channel (sum relu(h) == 0 exactly, i.e. h <= 0 at every voxel) has dh = [h > 0] (...) = 0 whatever its
+  // coefficients are; 2 / (0 + 1e-8) would make them 1e13 times a live channel's, and the range scale of the
+  // split-fp16 head gradient (head_dh_scale_kernel: one power of two for all channels) would push every live channel
+  // below fp16's range.  Zero coefficients give the same (zero) gradient and leave the scale to the live channels.
+  if (sums[ch * 4] == 0.f) {
+    g[ch * 4 + 0] = g[ch * 4 + 1] = g[ch * 4 + 2] = g[ch * 4 + 3] = 0.f;
+    return;
+  }
   const float den = sums[ch * 4] + 1e-8f;
   const float k2 = 2.f / den;
   const float gz = dpts[ch * 3] * k2, gy = dpts[ch * 3 + 1] * k2, gx = dpts[ch * 3 + 2] * k2;

@@ -369,6 +369,51 @@ def test_fused_head_power_output_and_gradient(mode):
         B.set_conv_mode(old)
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "f32"])
+def test_fused_head_dead_and_faint_keypoint_channels(mode):
+    """Keypoint channels whose logits are <= 0 everywhere (sum relu(h) == 0: the center of mass is 0 / 1e-8) or positive
+    at a single voxel happen after a few training steps.  Their 1 / mass gradient coefficients are up to 1e13 times a
+    live channel's; they must not cost the live channels their gradient (one power-of-two range scale for all channels
+    pushed them below fp16's range: 74 % error on the final conv's weight gradient at 256^3 before the fix)."""
+    from keymorph_amd import backbone_ops as B
+    from oracle import keymorph_oracle as O
+    N, Cin, Cout, dims = 2, 16, 40, (6, 8, 32)
+    g = gen(29)
+    x = torch.randn(N, *dims, Cin, generator=g).abs()
+    w = torch.randn(Cout, Cin, 1, 1, 1, generator=g) / np.sqrt(Cin)
+    b = 0.3 * torch.randn(Cout, generator=g)
+    w[3], b[3] = -w[3].abs(), -1.0                     # dead in every sample: non-negative features, negative weights
+    w[17], b[17] = -w[17].abs(), -0.5
+    w[9] = -w[9].abs()                                 # faint: positive at exactly one voxel of sample 0
+    b[9] = 1e-3 - float((w[9].reshape(-1) * x[0, 2, 3, 5]).sum())
+    x[0, 2, 3, 5] *= 0.5                               # ... by making that voxel's (negative) response the least negative
+    b[9] = 1e-3 - float((w[9].reshape(-1) * x[0, 2, 3, 5]).sum())
+    cot = torch.randn(N, Cout, 3, generator=g)
+    R = [t.clone().double().requires_grad_(True) for t in (x, w, b)]
+    h = F.conv3d(ncdhw(R[0]), R[1], R[2])
+    mass = F.relu(h).flatten(2).sum(-1).detach()
+    assert float(mass[:, 3].max()) == 0 and float(mass[:, 17].max()) == 0
+    assert 0 < float(mass[0, 9]) < 1e-2 * float(mass.median())
+    (O.center_of_mass(h, "ij") * cot.double()).sum().backward()
+    old = B.CONV_MODE
+    try:
+        B.set_conv_mode(mode)
+        A = [t.to(DEV).requires_grad_(True) for t in (x, w, b)]
+        pa = B.head_com(*A)
+        (pa * cot.to(DEV)).sum().backward()
+        live = [k for k in range(Cout) if k not in (3, 9, 17)]
+        close(pa[:, live], O.center_of_mass(h, "ij").detach()[:, live], 5e-6, 1e-5)
+        gw, rw = A[1].grad.cpu().double(), R[1].grad
+        for k in live:                                 # every live channel keeps its own relative accuracy
+            assert float((gw[k] - rw[k]).norm() / rw[k].norm()) < 2e-3, (k, mode)
+        assert float(gw[3].abs().max()) == 0 and float(gw[17].abs().max()) == 0
+        close(A[2].grad[live], R[2].grad[live], 2e-4 * float(R[2].grad[live].abs().max()), 1e-3)
+        gx, rx = A[0].grad.cpu().double(), R[0].grad
+        assert float((gx - rx).norm() / rx.norm()) < 2e-3
+    finally:
+        B.set_conv_mode(old)
+
+
 @pytest.mark.parametrize("cfg", [(1, 16, 32, (6, 10, 40), 8), (2, 8, 8, (5, 7, 9), 8), (1, 1, 4, (8, 8, 8), 1),
                                  (1, 48, 64, (4, 9, 33), 8), (1, 12, 20, (4, 4, 6), 4)])
 def test_conv_arithmetic_modes_vs_fp64(cfg):

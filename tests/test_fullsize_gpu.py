@@ -186,39 +186,49 @@ def test_training_step_decreases_loss(world):
 
 
 def test_two_pairs_per_gpu_equal_two_single_pairs(world):
-    """BASELINE configs[1] runs 2 pairs per GPU: one fwd+bwd over the batch of 2 gives each pair's keypoints / grid and
-    the MEAN of the two single-pair losses and parameter gradients (norms are per sample; nothing couples the pairs).
-    Checked through the affine aligner, which is well conditioned; at lambda = 0 the 512 clustered keypoints of this
-    random-init network turn 1e-7 keypoint differences into 1e-2 grid differences (test_tps_interpolates_keypoints), so the
-    tps_0 leg checks the keypoints, finiteness and that the batch loss lies between the two single-pair losses' range."""
+    """BASELINE configs[1] runs 2 pairs per GPU: one pass over the batch of 2 pairs gives each pair's keypoints, grid and
+    loss, and the SUM of the two single-pair parameter gradients (norms are per sample; nothing couples the pairs).
+    The gradient is taken through a fixed linear read-out of the keypoints: through the keypoint fit the 512 clustered
+    keypoints of this random-init network amplify 1e-7 keypoint differences by the fit's condition number
+    (test_tps_interpolates_keypoints), which says nothing about the kernels.  Grid / loss go through the affine aligner
+    for the same reason; the tps_0 leg checks finiteness."""
     from keymorph_amd import ops, synthetic
     km = world["km"].train()
     f2, m2 = synthetic.make_pair(SIZE, 5, torch.device(DEV))
     F, M = torch.cat([world["img_f"], f2]), torch.cat([world["img_m"], m2])
+    g = torch.Generator().manual_seed(3)
+    cot = torch.randn(2, 2, K, 3, generator=g).to(DEV)            # (pair, fixed / moving, keypoint, axis)
 
-    def run(f, m, tt):
+    def backbone_grads(pairs):
         km.zero_grad(set_to_none=True)
-        r = km(f, m, transform_type=tt, return_aligned_points=False)[tt]
-        loss, _ = ops.warp_mse(m, r["grid"], f)
-        loss.backward()
-        g = torch.cat([p.grad.reshape(-1) for p in km.parameters()]).clone()
-        return float(loss.detach()), g, r["points_f"].detach().clone(), r["grid"].detach().clone()
+        imgs = torch.cat([F[pairs], M[pairs]])                   # [fixed...; moving...] as KeyMorph.forward batches them
+        pts = km.get_keypoints(imgs)
+        c = torch.cat([cot[pairs, 0], cot[pairs, 1]])
+        (pts * c).sum().backward()
+        return pts.detach().clone(), torch.cat([p.grad.reshape(-1) for p in km.parameters()]).clone()
+
+    def register(f, m, tt):
+        with torch.no_grad():
+            r = km(f, m, transform_type=tt, return_aligned_points=False)[tt]
+            loss, _ = ops.warp_mse(m, r["grid"], f)
+        return float(loss), r["grid"]
 
     try:
-        lb, gb, pb, grid_b = run(F, M, "affine")
-        singles = [run(F[i:i + 1], M[i:i + 1], "affine") for i in range(2)]
-        lt, gt, pt, grid_t = run(F, M, "tps_0")
+        pb, gb = backbone_grads([0, 1])
+        singles = [backbone_grads([i]) for i in range(2)]
+        km.zero_grad(set_to_none=True)
+        lb, grid_b = register(F, M, "affine")
+        ls = [register(F[i:i + 1], M[i:i + 1], "affine") for i in range(2)]
+        lt, grid_t = register(F, M, "tps_0")
     finally:
         km.zero_grad(set_to_none=True)
         km.eval()
-    for i, (li, gi, pi, grid_i) in enumerate(singles):
-        close(pb[i:i + 1], pi, 2e-6)
-        close(grid_b[i:i + 1], grid_i, 2e-4)
-        close(pt[i:i + 1], pi, 2e-6)                       # the keypoints do not depend on the aligner
-    lm = 0.5 * (singles[0][0] + singles[1][0])
+    for i, (pi, gi) in enumerate(singles):
+        close(pb[[i, 2 + i]], pi, 2e-6)
+        close(grid_b[i:i + 1], ls[i][1], 2e-4)
+    gs = singles[0][1] + singles[1][1]
+    rel = float((gb - gs).norm() / gs.norm())
+    assert bool(torch.isfinite(gb).all()) and float(gb.abs().max()) > 0 and rel < 1e-3, rel
+    lm = 0.5 * (ls[0][0] + ls[1][0])
     assert abs(lb - lm) <= 1e-5 * max(1.0, abs(lm)), (lb, lm)
-    gm = 0.5 * (singles[0][1] + singles[1][1])
-    rel = float((gb - gm).norm() / gm.norm())
-    assert bool(torch.isfinite(gb).all()) and rel < 2e-2, rel
-    assert np.isfinite(lt) and bool(torch.isfinite(gt).all()) and bool(torch.isfinite(grid_t).all())
-    assert float(gt.abs().max()) > 0
+    assert np.isfinite(lt) and bool(torch.isfinite(grid_t).all())
