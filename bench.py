@@ -13,6 +13,7 @@ kernel (the 3x3x3 conv, fp32 results from split-bf16 MFMA) and `cpu_baseline` (t
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -224,6 +225,10 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(loss.item())
+    # a step timed on non-finite parameters would be a measurement of nothing (lambda = 0 TPS is singular once two
+    # keypoints coincide): refuse to report it
+    if not (math.isfinite(loss_val) and bool(torch.isfinite(flat.flat).all()) and bool(torch.isfinite(flat.grad).all())):
+        raise SystemExit(f"bench.py: non-finite loss / parameters / gradients after the timed steps (loss {loss_val})")
 
     def timed(nsteps, **kw):
         sync()

@@ -16,7 +16,7 @@ lr = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-3
 train_mode = sys.argv[5] if len(sys.argv) > 5 else "f16x3"
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-model = build_model(size, dev)
+model = build_model(int(os.environ.get("KEYPOINTS", "512")), dev)     # bench.build_model takes the keypoint count
 flat = parallel.FlatParams(model.parameters())
 opt = parallel.FusedAdam(flat, lr=lr)
 pairs = [synthetic.make_pair(size, i, dev) for i in range(2)]
