@@ -10,6 +10,7 @@
 // All GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32).  M = 32 voxels, N = 32 keypoint channels: the MFMA C
 // layout (col = channel = lane, row = voxel) makes the center-of-mass sums per-lane accumulations, and its
 // registers are directly the A operand of the dW product (k-pair = voxels rho, rho+4).
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -649,7 +650,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void headcom_bwd_w_bf_k
                                                                    float* __restrict__ pb /* (nslab, Cout) */, int N,
                                                                    long long V, int Cin, int Cout, int CoutP, Dims d,
                                                                    int tiles_per_slab, int ngroups,
-                                                                   const float* __restrict__ hs) {
+                                                                   const float* __restrict__ hs,
+                                                                   const int* __restrict__ gate, int want) {
+  if (gate && *gate != want) return;         // the other arithmetic runs this backward (head_dh_scale_kernel)
   extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
   // one buffer: sF [TERMS][64 voxels][128 B] + sFT [TERMS][64 ci][128 B] (columns = sigma(voxel)) + sC [64]
   constexpr int WBUF = 2 * TERMS * WVT * 128 + WVT * 16;
@@ -798,7 +801,9 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_bf_kernel(const fl
                                                                         float* __restrict__ dfeat, long long V,
                                                                         int Cin, int Cout, int CoutP, Dims d,
                                                                         const float* __restrict__ hs, int mask_dfeat,
-                                                                        unsigned* __restrict__ amax /* max |dfeat| bits | NULL */) {
+                                                                        unsigned* __restrict__ amax /* max |dfeat| bits | NULL */,
+                                                                        const int* __restrict__ gate, int want) {
+  if (gate && *gate != want) return;         // the other arithmetic runs this backward (head_dh_scale_kernel)
   extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
   constexpr int IMG = TERMS * 64 * 128;            // one image of one block: [TERMS][64 rows][128 B]
   constexpr int BUF = 2 * IMG + WBLK * 32;         // wkp block + wt block + (g float4, bias) per channel
@@ -1034,15 +1039,34 @@ __global__ void head_scales_one_kernel(float* __restrict__ hs) {
   if (threadIdx.x < 8) hs[threadIdx.x] = 1.f;
 }
 // |dh| <= |g0| + |gz| + |gy| + |gx| (the normalised coordinates lie in [0, 1]): range scale of the head gradient
-__global__ __launch_bounds__(256) void head_dh_scale_kernel(const float* __restrict__ g, int NK, float* __restrict__ out2) {
+// Also decides which arithmetic runs the backward.  One power-of-two scale for all channels keeps a channel whose bound
+// is b at a relative precision of max(2^-22, 2^-40 B / b) (B = the largest bound: below B 2^-18 the low fp16 term is
+// denormal).  A live channel with a single faint voxel has b ~ 1 / mass: when any live channel sits more than 2^24 below
+// B, gate = 1 and the three-term bf16 kernels (8 exponent bits, no range scale) run instead of the split-fp16 ones --
+// both sets are launched, each returns at once unless the gate names it.
+__global__ __launch_bounds__(256) void head_dh_scale_kernel(const float* __restrict__ g, int NK, float* __restrict__ out2,
+                                                            int* __restrict__ gate) {
   float m = 0.f;
   for (int i = threadIdx.x; i < NK; i += 256)
     m = fmaxf(m, fabsf(g[i * 4]) + fabsf(g[i * 4 + 1]) + fabsf(g[i * 4 + 2]) + fabsf(g[i * 4 + 3]));
   __shared__ float red[4];
+  __shared__ int wide;
+  if (threadIdx.x == 0) wide = 0;
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) range_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), out2);
+  const float B = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (threadIdx.x == 0) range_scale(B, out2);
+  if (gate) {
+    int w = 0;
+    for (int i = threadIdx.x; i < NK; i += 256) {
+      const float b = fabsf(g[i * 4]) + fabsf(g[i * 4 + 1]) + fabsf(g[i * 4 + 2]) + fabsf(g[i * 4 + 3]);
+      w |= (b > 0.f && b < B * 5.9604645e-8f) ? 1 : 0;         // 2^-24
+    }
+    if (w) atomicOr(&wide, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) *gate = wide;
+  }
 }
 __global__ void head_scales_copy_kernel(const float* __restrict__ src, float* __restrict__ dst) {
   if (threadIdx.x < 4) dst[threadIdx.x] = src[threadIdx.x];
@@ -1146,35 +1170,56 @@ static int head_bwd_bf(const float* dpts, const float* dpower, const float* feat
   float* pw = (float*)base;
   float* pb = pw + (size_t)p.nslab_w * Cout * Cin;
   float* hs = (float*)((char*)pb + align256((size_t)p.nslab_w * Cout * sizeof(float)));
+  // TERMS == 2 only: the three-term images / unit scales / gate of the wide-dynamic-range fallback
+  const HeadBfPlan p3 = head_bf_plan(N, V, Cout, 3);
+  void* img3 = (char*)hs + 256;
+  float* hs3 = (float*)((char*)img3 + align256(p3.img_bytes));
+  int* gate = TERMS == 2 ? (int*)((char*)hs3 + 128) : nullptr;
   int rc = head_scales<TERMS>(feat, (long long)N * V * Cin, w, (long long)Cout * Cin, hs, s, scales_in);
   if (rc) return rc;
   rc = head_pack<TERMS>(w, Cout, Cin, p, img, hs, s);
   if (rc) return rc;
-  const __bf16* wk = (const __bf16*)img;
-  const __bf16* wkp = wk + (size_t)TERMS * p.CoutP * 64;
-  const __bf16* wt = wkp + (size_t)TERMS * p.CoutP * 64;
   Dims d{D, H, W};
   headcom_coef_kernel<<<ceil_div(N * Cout, 64), 64, 0, s>>>(dpts, dpower, sums, N * Cout, g);
-  if (TERMS == 2) head_dh_scale_kernel<<<1, 256, 0, s>>>(g, N * Cout, hs + 4);
-  if (dfeat) {
-    const size_t lds = 2 * ((size_t)2 * TERMS * 64 * 128 + WBLK * 32);
-    hipError_t e = hipFuncSetAttribute((const void*)headcom_bwd_feat_bf_kernel<TERMS>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    headcom_bwd_feat_bf_kernel<TERMS><<<dim3(ceil_div(V, 256), N), BF_TPB, lds, s>>>(feat, wkp, wt, bias, g, dfeat, V,
-                                                                                   Cin, Cout, p.CoutP, d, hs, mask_dfeat,
-                                                                                   reinterpret_cast<unsigned*>(dfeat_scale2));
-    if (dfeat_scale2) kmh_absmax::final_kernel<<<1, 1, 0, s>>>(dfeat_scale2, 0.f);
+  if (TERMS == 2) head_dh_scale_kernel<<<1, 256, 0, s>>>(g, N * Cout, hs + 4, gate);
+
+  auto launch = [&](auto tag, const HeadBfPlan& pl, const void* img_, const float* hs_, int want) -> int {
+    constexpr int T = decltype(tag)::value;
+    const __bf16* wk = (const __bf16*)img_;
+    const __bf16* wkp = wk + (size_t)T * pl.CoutP * 64;
+    const __bf16* wt = wkp + (size_t)T * pl.CoutP * 64;
+    if (dfeat) {
+      const size_t lds = 2 * ((size_t)2 * T * 64 * 128 + WBLK * 32);
+      hipError_t e = hipFuncSetAttribute((const void*)headcom_bwd_feat_bf_kernel<T>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      headcom_bwd_feat_bf_kernel<T><<<dim3(ceil_div(V, 256), N), BF_TPB, lds, s>>>(
+          feat, wkp, wt, bias, g, dfeat, V, Cin, Cout, pl.CoutP, d, hs_, mask_dfeat,
+          reinterpret_cast<unsigned*>(dfeat_scale2), gate, want);
+    }
+    if (dw) {
+      const size_t lds = 2 * ((size_t)2 * T * WVT * 128 + WVT * sizeof(float4));   // double buffered
+      const bool rows = W % 32 == 0 && V % WVT == 0 && V < (1ll << 31);
+      auto kern = pl.nwv_w == 8 ? (rows ? headcom_bwd_w_bf_kernel<T, true, 8> : headcom_bwd_w_bf_kernel<T, false, 8>)
+                                : (rows ? headcom_bwd_w_bf_kernel<T, true, 4> : headcom_bwd_w_bf_kernel<T, false, 4>);
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      kern<<<dim3(pl.nslab_w * pl.ngroups_w), 64 * pl.nwv_w, lds, s>>>(feat, wk, bias, g, pw, pb, N, V, Cin, Cout, pl.CoutP,
+                                                                      d, pl.tps_w, pl.ngroups_w, hs_, gate, want);
+    }
+    return KMH_LAUNCH_CHECK();
+  };
+  rc = launch(std::integral_constant<int, TERMS>{}, p, img, hs, 0);
+  if (rc) return rc;
+  if (TERMS == 2) {
+    head_scales_one_kernel<<<1, 64, 0, s>>>(hs3);
+    rc = head_pack<3>(w, Cout, Cin, p3, img3, hs3, s);
+    if (rc) return rc;
+    rc = launch(std::integral_constant<int, 3>{}, p3, img3, hs3, 1);
+    if (rc) return rc;
   }
+  if (dfeat && dfeat_scale2) kmh_absmax::final_kernel<<<1, 1, 0, s>>>(dfeat_scale2, 0.f);
   if (dw) {
-    const size_t lds = 2 * ((size_t)2 * TERMS * WVT * 128 + WVT * sizeof(float4));   // double buffered
-    const bool rows = W % 32 == 0 && V % WVT == 0 && V < (1ll << 31);
-    auto kern = p.nwv_w == 8 ? (rows ? headcom_bwd_w_bf_kernel<TERMS, true, 8> : headcom_bwd_w_bf_kernel<TERMS, false, 8>)
-                             : (rows ? headcom_bwd_w_bf_kernel<TERMS, true, 4> : headcom_bwd_w_bf_kernel<TERMS, false, 4>);
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    kern<<<dim3(p.nslab_w * p.ngroups_w), 64 * p.nwv_w, lds, s>>>(feat, wk, bias, g, pw, pb, N, V, Cin, Cout, p.CoutP, d,
-                                                                  p.tps_w, p.ngroups_w, hs);
     int nb = ceil_div((long long)Cout * Cin, 256);
     if (nb > 1024) nb = 1024;
     headcom_reduce_kernel<<<nb, 256, 0, s>>>(pw, p.nslab_w, (long long)Cout * Cin, dw);
@@ -1190,8 +1235,10 @@ KMH_API size_t kmh_headcom_fwd_bf_ws_bytes(int N, long long V, int Cout, int ter
 }
 KMH_API size_t kmh_headcom_bwd_bf_ws_bytes(int N, long long V, int Cin, int Cout, int terms) {
   const HeadBfPlan p = head_bf_plan(N, V, Cout, terms);
+  const HeadBfPlan p3 = head_bf_plan(N, V, Cout, 3);       // the fallback's images, unit scales and gate (terms == 2)
   return align256((size_t)N * Cout * 4 * sizeof(float)) + align256(p.img_bytes) +
-         (size_t)p.nslab_w * (size_t)Cout * Cin * sizeof(float) + align256((size_t)p.nslab_w * Cout * sizeof(float)) + 512;
+         (size_t)p.nslab_w * (size_t)Cout * Cin * sizeof(float) + align256((size_t)p.nslab_w * Cout * sizeof(float)) + 512 +
+         align256(p3.img_bytes) + 512;
 }
 
 /* same contracts as kmh_headcom_fwd / kmh_headcom_bwd; Cin % 4 == 0, Cin <= 64 */

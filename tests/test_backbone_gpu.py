@@ -384,16 +384,15 @@ def test_fused_head_dead_and_faint_keypoint_channels(mode):
     b = 0.3 * torch.randn(Cout, generator=g)
     w[3], b[3] = -w[3].abs(), -1.0                     # dead in every sample: non-negative features, negative weights
     w[17], b[17] = -w[17].abs(), -0.5
-    w[9] = -w[9].abs()                                 # faint: positive at exactly one voxel of sample 0
-    b[9] = 1e-3 - float((w[9].reshape(-1) * x[0, 2, 3, 5]).sum())
-    x[0, 2, 3, 5] *= 0.5                               # ... by making that voxel's (negative) response the least negative
-    b[9] = 1e-3 - float((w[9].reshape(-1) * x[0, 2, 3, 5]).sum())
+    w[9] = -w[9].abs()                                 # faint: positive (1e-3) at exactly one voxel of one sample
+    resp9 = (x.double() * w[9].reshape(-1).double()).sum(-1)          # (N, D, H, W), all negative
+    b[9] = 1e-3 - float(resp9.max())
     cot = torch.randn(N, Cout, 3, generator=g)
     R = [t.clone().double().requires_grad_(True) for t in (x, w, b)]
     h = F.conv3d(ncdhw(R[0]), R[1], R[2])
     mass = F.relu(h).flatten(2).sum(-1).detach()
     assert float(mass[:, 3].max()) == 0 and float(mass[:, 17].max()) == 0
-    assert 0 < float(mass[0, 9]) < 1e-2 * float(mass.median())
+    assert 0 < float(mass[:, 9].max()) < 1e-4 * float(mass.median())
     (O.center_of_mass(h, "ij") * cot.double()).sum().backward()
     old = B.CONV_MODE
     try:
@@ -410,6 +409,22 @@ def test_fused_head_dead_and_faint_keypoint_channels(mode):
         close(A[2].grad[live], R[2].grad[live], 2e-4 * float(R[2].grad[live].abs().max()), 1e-3)
         gx, rx = A[0].grad.cpu().double(), R[0].grad
         assert float((gx - rx).norm() / rx.norm()) < 2e-3
+        # an extremely faint channel (mass 1e-9: its coefficients are ~1e14 times a live channel's -- beyond what one
+        # range scale can carry next to the others): the split-fp16 mode hands this backward to the three-term kernels
+        b2 = b.clone()
+        b2[9] = float(np.float32(1e-7 - float(resp9.max())))
+        R2 = [t.clone().double().requires_grad_(True) for t in (x, w, b2)]
+        h2 = F.conv3d(ncdhw(R2[0]), R2[1], R2[2])
+        m2 = F.relu(h2).flatten(2).sum(-1).detach()
+        m9 = float(m2[:, 9].max())
+        if 0 < m9 < 1e-5:                               # (fp32 rounding of the bias may kill the voxel: then nothing to test)
+            (O.center_of_mass(h2, "ij") * cot.double()).sum().backward()
+            A2 = [t.to(DEV).requires_grad_(True) for t in (x, w, b2)]
+            (B.head_com(*A2) * cot.to(DEV)).sum().backward()
+            gw2, rw2 = A2[1].grad.cpu().double(), R2[1].grad
+            for k in live:
+                # (measured: 9e-6 with the hand-over, 1.5e-1 without it)
+                assert float((gw2[k] - rw2[k]).norm() / rw2[k].norm()) < 5e-4, (k, mode, "extremely faint channel")
     finally:
         B.set_conv_mode(old)
 

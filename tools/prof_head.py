@@ -4,6 +4,9 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("KMH_LIB"):      # A/B runs against another build of the library (tools/build_old_lib.sh)
+    from keymorph_amd import _lib
+    _lib.LIBPATH = os.environ["KMH_LIB"]
 from keymorph_amd import backbone_ops as bo
 
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 256
