@@ -1,4 +1,5 @@
-for r in 1 2; do
-echo "new: $(python tools/prof_head.py 128 64 512 4)"
-echo "old: $(KMH_LIB=keymorph_amd/lib/ab/libkeymorph_hip_old.so python tools/prof_head.py 128 64 512 4)"
+export KMH_TIME=1
+for cfg in "256 16 32" "128 32 32" "128 64 64"; do
+  echo "== $cfg base   : $(python tools/prof_layer.py $cfg f16x3 nomask 2>/dev/null | grep -v "done\|wgrad" | tr '\n' ' ')"
+  echo "== $cfg nostore: $(KMH_LIB=keymorph_amd/lib/ab/libkeymorph_hip_old.so python tools/prof_layer.py $cfg f16x3 nomask 2>/dev/null | grep -v "done\|wgrad" | tr '\n' ' ')"
 done
