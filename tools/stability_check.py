@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 for mode in ("f16x3",):
     B.set_conv_mode(mode)
     torch.manual_seed(0)
-    model = build_model(64, dev)
+    model = build_model(64, dev)          # 64 KEYPOINTS (bench.build_model takes the keypoint count), 64^3 volumes below
     flat = parallel.FlatParams(model.parameters())
     opt = parallel.FusedAdam(flat, lr=float(sys.argv[1]) if len(sys.argv) > 1 else 1e-3)
     pairs = [synthetic.make_pair(64, i, dev) for i in range(2)]
