@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .transformations import AffineTransform, _bottom_row
+from .transformations import AffineTransform
 from .utils import convert_points_norm2real, convert_points_real2norm
 
 

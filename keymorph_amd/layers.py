@@ -1,5 +1,4 @@
 """Keypoint layers (keymorph/layers.py:30-134)."""
-import torch
 import torch.nn as nn
 
 from . import ops

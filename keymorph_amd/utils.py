@@ -6,7 +6,6 @@ plain tensor algebra, as SURVEY.md section 8 row a16 prescribes.
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
 

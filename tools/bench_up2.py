@@ -16,7 +16,6 @@ for (D, Cs, Cl, Cout) in ((128, 64, 128, 64), (64, 128, 256, 128)):
     e1.record(); torch.cuda.synchronize()
     print(f"up2_dgrad D={D} Cl={Cl} Cout={Cout}: {e0.elapsed_time(e1)/5:.3f} ms")
 
-import os
 from keymorph_amd import _lib
 lib = _lib.load()
 for (D, Cs, Cl, Cout) in ((128, 64, 128, 64), (64, 128, 256, 128)):
