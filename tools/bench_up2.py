@@ -1,6 +1,9 @@
 """time the up2 kernels at the bench shapes (N = 4): decoder levels 128^3 (64 + 128 -> 64) and 64^3 (128 + 256 -> 128)"""
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, '.')
+if os.environ.get('KMH_LIB'):
+    from keymorph_amd import _lib as _l
+    _l.LIBPATH = os.environ['KMH_LIB']
 from keymorph_amd import backbone_ops as B
 B.set_conv_mode("f16x3")
 dev = "cuda"
