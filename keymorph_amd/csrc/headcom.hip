@@ -1041,9 +1041,13 @@ __global__ void head_scales_one_kernel(float* __restrict__ hs) {
 // |dh| <= |g0| + |gz| + |gy| + |gx| (the normalised coordinates lie in [0, 1]): range scale of the head gradient
 // Also decides which arithmetic runs the backward.  One power-of-two scale for all channels keeps a channel whose bound
 // is b at a relative precision of max(2^-22, 2^-40 B / b) (B = the largest bound: below B 2^-18 the low fp16 term is
-// denormal).  A live channel with a single faint voxel has b ~ 1 / mass: when any live channel sits more than 2^24 below
-// B, gate = 1 and the three-term bf16 kernels (8 exponent bits, no range scale) run instead of the split-fp16 ones --
-// both sets are launched, each returns at once unless the gate names it.
+// denormal; measured on the worst rows it is ~2^6 worse than that, the values of a channel lying below its bound).  A
+// live channel with a single faint voxel has b ~ 1 / mass: when any live channel sits more than 2^30 below B, gate = 1
+// and the three-term bf16 kernels (8 exponent bits, no range scale) run instead of the split-fp16 ones -- both sets are
+// launched, each returns at once unless the gate names it.  (2^30, not less: at a fresh initialisation with lambda = 0
+// the bounds of the 2048 (sample, keypoint) channels already span 2^28 -- median 2^-20 of the largest -- because the
+// keypoint gradients do; those weakest rows then carry ~1 % error on a gradient 2^-28 of the largest, which Adam's
+// per-parameter normalisation does not see, and the step keeps its split-fp16 speed.)
 __global__ __launch_bounds__(256) void head_dh_scale_kernel(const float* __restrict__ g, int NK, float* __restrict__ out2,
                                                             int* __restrict__ gate) {
   float m = 0.f;
@@ -1061,7 +1065,7 @@ __global__ __launch_bounds__(256) void head_dh_scale_kernel(const float* __restr
     int w = 0;
     for (int i = threadIdx.x; i < NK; i += 256) {
       const float b = fabsf(g[i * 4]) + fabsf(g[i * 4 + 1]) + fabsf(g[i * 4 + 2]) + fabsf(g[i * 4 + 3]);
-      w |= (b > 0.f && b < B * 5.9604645e-8f) ? 1 : 0;         // 2^-24
+      w |= (b > 0.f && b < B * 9.3132257e-10f) ? 1 : 0;        // 2^-30
     }
     if (w) atomicOr(&wide, 1);
     __syncthreads();
