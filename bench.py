@@ -277,6 +277,10 @@ def main():
             if meta and "shape" in meta:
                 ms = ea.elapsed_time(eb)
                 print(f"# {name:18s} {str(meta['shape']):34s} {ms:8.3f} ms {meta['flops'] / ms / 1e9:7.1f} TF", file=sys.stderr)
+    # algorithmic bytes of the dominant kernel's launches: input + output tensor of each, once (fp32)
+    conv_name = "kmh_conv3d_fwd" if a.conv == "f32" else "kmh_conv3d_fwd_bf"
+    conv_alg_bytes = [4.0 * m["shape"][0] * m["shape"][1] * m["shape"][2] * m["shape"][3] * (m["shape"][4] + m["shape"][5])
+                      for name, _, _, m in _lib.profiler.records if name == conv_name and m and "shape" in m]
     _lib.profiler.enabled = False
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
 
@@ -319,6 +323,7 @@ def main():
                 "launches": conv["calls"],
                 "avg_launch_ms": conv["ms"] / max(conv["calls"], 1),
                 "share_of_step_kernel_time": conv["ms"] / max(total_ms, 1e-9),
+                "algorithmic_bytes_per_launch": (sum(conv_alg_bytes) / len(conv_alg_bytes)) if conv_alg_bytes else None,
             },
             "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
             "wgrad_tflops": wg["flops"] / max(wg["ms"], 1e-9) / 1e9,
