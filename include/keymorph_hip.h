@@ -171,6 +171,15 @@ int kmh_conv3d_fwd_bf(const float* x, const float* scale, const float* shift, co
                       const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout, int relu_in,
                       int relu_out, int terms, int rows_per_wave, const float* ascale, const float* wscale,
                       void* stats_ws, double* stats_out, int in_blocked, const float* addend, void* stream);
+/* Kernel selection of kmh_conv3d_fwd_bf (the reference has one conv3d: keymorph/unet3d/buildingblocks.py:46-58; this
+ * only chooses between two implementations with bit-identical results).  mode 0: conv3_fwd_bf_kernel always; 1: the
+ * LDS-DMA kernel conv3_fwd_g_kernel for launches of >= 512 bricks (default; KEYMORPH_FWD_G sets the initial value);
+ * 2: conv3_fwd_g_kernel whenever its preconditions hold (parity tests on small / ragged volumes).  Returns the
+ * previous mode, -22 for a bad argument. */
+int kmh_conv3d_fwd_bf_set_dispatch(int mode);
+/* the kernel kmh_conv3d_fwd_bf would launch for this call now: 0 conv3_fwd_bf_kernel, 1 / 2 conv3_fwd_g_kernel with a
+ * 32- / 64-wide output-channel tile, 3 its z-paired variant (Cout <= 16) */
+int kmh_conv3d_fwd_bf_variant(int N, int D, int H, int W, int Cin, int Cout, int terms, int has_mask, int has_addend);
 /* addend (like y) | NULL: added to the result before the activation and the statistics (Cout > 16).
  * Decoder's first convolution without the upsampled tensor: the 27 taps over a nearest-x2 upsampled channel fall on
  * 2 x 2 x 2 low-resolution voxels per output parity, so kmh_conv3d_up2_fwd computes the upsampled channels'

@@ -24,6 +24,7 @@
 //   * the filter is pre-packed as [cin/8][term][step][half][cout][8] 16-bit values, so a B fragment is one
 //     512-byte-per-half-wave global_load_dwordx4 from L2, prefetched through a register ring;
 //   * the epilogue can emit the (sum, sum of squares) per channel that the next GroupNorm needs.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include "common.h"
@@ -1454,14 +1455,46 @@ static int launch_fwd_g(const float* x, const float* scale, const float* shift, 
 
 // the LDS-DMA kernel's preconditions: fp16 split, whole 8-channel chunks, no fused mask operand, and enough bricks to
 // give every CU several of them
-static bool fwd_g_ok(const float* mask, const float* addend, int N, int D, int H, int W, int Cin, int Cout, int terms) {
-  static const int mode = getenv("KEYMORPH_FWD_G") ? atoi(getenv("KEYMORPH_FWD_G")) : 1;     // 0: off (A/B runs)
+// 0: never, 1: when the launch has >= 512 bricks (default), 2: whenever the preconditions hold (parity tests force the
+// kernel onto small / ragged volumes this way).  Initialised from KEYMORPH_FWD_G, changed by kmh_conv3d_fwd_bf_set_dispatch.
+static std::atomic<int> g_fwd_g_mode{-1};
+static int fwd_g_mode() {
+  int m = g_fwd_g_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    m = getenv("KEYMORPH_FWD_G") ? atoi(getenv("KEYMORPH_FWD_G")) : 1;
+    if (m < 0 || m > 2) m = 1;
+    g_fwd_g_mode.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+
+static bool fwd_g_ok(bool mask, bool addend, int N, int D, int H, int W, int Cin, int Cout, int terms) {
+  const int mode = fwd_g_mode();
   if (!mode || terms != 2 || mask || (Cin & 7) || (Cout & 3)) return false;
   if (use_zpair(Cout) && addend) return false;
   if ((long long)D * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31)) return false;          // 32-bit element offsets
   const long long wgs = (long long)N * ceil_div(W, TX) * ceil_div(H, GTY) * ceil_div(D, GTZ) *
                         (use_zpair(Cout) ? 1 : ceil_div(Cout, 64));
   return wgs >= (mode == 2 ? 1 : 512);
+}
+
+/* Kernel selection of kmh_conv3d_fwd_bf, settable at run time: mode 0 = conv3_fwd_bf_kernel always, 1 = the LDS-DMA
+ * kernel (conv3_fwd_g_kernel) for launches of >= 512 bricks (default), 2 = conv3_fwd_g_kernel whenever its
+ * preconditions hold, whatever the size.  Returns the previous mode (-22 for a bad argument). */
+KMH_API int kmh_conv3d_fwd_bf_set_dispatch(int mode) {
+  if (mode < 0 || mode > 2) return -22;
+  const int old = fwd_g_mode();
+  g_fwd_g_mode.store(mode, std::memory_order_relaxed);
+  return old;
+}
+
+/* Which kernel kmh_conv3d_fwd_bf launches for this call under the current dispatch mode:
+ * 0 conv3_fwd_bf_kernel, 1 conv3_fwd_g_kernel<1,false>, 2 conv3_fwd_g_kernel<2,false>, 3 conv3_fwd_g_kernel<1,true>
+ * (z-paired, Cout <= 16). */
+KMH_API int kmh_conv3d_fwd_bf_variant(int N, int D, int H, int W, int Cin, int Cout, int terms, int has_mask,
+                                      int has_addend) {
+  if (!fwd_g_ok(has_mask != 0, has_addend != 0, N, D, H, W, Cin, Cout, terms)) return 0;
+  return use_zpair(Cout) ? 3 : (Cout > 32 ? 2 : 1);
 }
 
 static inline int fwd_bf_rows(int Cout, int rows_per_wave) {   // smallest brick height in y of the variants that may run
@@ -1503,7 +1536,7 @@ KMH_API int kmh_conv3d_fwd_bf(const float* x, const float* scale, const float* s
   // registers plus 8 staging descriptors and is 4 % slower: not instantiated.)
   static const bool no_deep = getenv("KEYMORPH_FWD_NO_DEEP") != nullptr;     // A/B measurements only
   const bool deep = !no_deep && terms == 2 && Cout <= 32 && D >= 16 && (long long)D * H * W >= (1ll << 21);
-  if (fwd_g_ok(mask, addend, N, D, H, W, Cin, Cout, terms)) {
+  if (fwd_g_ok(mask != nullptr, addend != nullptr, N, D, H, W, Cin, Cout, terms)) {
     if (use_zpair(Cout)) return launch_fwd_g<1, true>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
     if (Cout > 32) return launch_fwd_g<2, false>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
     return launch_fwd_g<1, false>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);

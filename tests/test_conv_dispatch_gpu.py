@@ -1,0 +1,262 @@
+"""GPU: the convolution kernels the bench times, forced onto ragged multi-sample volumes.
+
+`conv3_fwd_g_kernel` (the LDS-DMA forward / data-gradient kernel, 38 % of the 256^3 step) is normally chosen only for
+launches of >= 512 bricks, i.e. never by the small op tests.  `kmh_conv3d_fwd_bf_set_dispatch(2)` forces it whenever
+its preconditions hold, so that its three instantiations (32-wide, 64-wide and z-paired output tiles) see partial
+32x8x4 bricks, partial 8x8 brick patches and several samples in one persistent work list -- checked here against an
+fp64 restatement of keymorph/unet3d/buildingblocks.py:46-78 (GroupNorm -> Conv3d(k3, p1, no bias) -> ReLU) and, bit for
+bit, against `conv3_fwd_bf_kernel` (the source claims identical arithmetic).  The wave-specialised weight gradient
+(`conv3_wgrad_ws_kernel`) runs on the same shapes."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+G_KERNEL = {1: "conv3_fwd_g_kernel<1,false>", 2: "conv3_fwd_g_kernel<2,false>", 3: "conv3_fwd_g_kernel<1,true>"}
+
+
+def gen(s):
+    return torch.Generator().manual_seed(s)
+
+
+def conv3_fp64(x, w):
+    """x (N,D,H,W,Cin) fp64, w (Cout,Cin,3,3,3) fp64 -> (N,D,H,W,Cout): zero-padded 3x3x3 cross-correlation as 27
+    shifted matrix products (differentiable; the fp64 truth of F.conv3d(padding=1), checked against it below)."""
+    N, D, H, W, Cin = x.shape
+    xp = F.pad(x, (0, 0, 1, 1, 1, 1, 1, 1))
+    y = None
+    for kz in range(3):
+        for ky in range(3):
+            for kx in range(3):
+                t = xp[:, kz:kz + D, ky:ky + H, kx:kx + W, :] @ w[:, :, kz, ky, kx].t()
+                y = t if y is None else y + t
+    return y
+
+
+def group_norm_fp64(x, G, gamma, beta, eps=1e-5):
+    N, D, H, W, C = x.shape
+    xg = x.reshape(N, D * H * W, G, C // G)
+    m = xg.mean(dim=(1, 3), keepdim=True)
+    v = xg.var(dim=(1, 3), keepdim=True, unbiased=False)
+    return ((xg - m) / torch.sqrt(v + eps)).reshape(N, D, H, W, C) * gamma + beta
+
+
+def rel(a, b):
+    return float((a.double() - b).abs().max()) / (float(b.abs().max()) + 1e-300)
+
+
+@pytest.fixture
+def dispatch():
+    """yields a setter for the forward kernel selection and restores the previous mode afterwards"""
+    from keymorph_amd import _lib
+    lib = _lib.load()
+    old = lib.kmh_conv3d_fwd_bf_set_dispatch(1)
+    lib.kmh_conv3d_fwd_bf_set_dispatch(old)
+
+    def set_mode(m):
+        assert lib.kmh_conv3d_fwd_bf_set_dispatch(m) >= 0
+    yield set_mode
+    lib.kmh_conv3d_fwd_bf_set_dispatch(old)
+
+
+def variant(N, D, H, W, Cin, Cout, mask=False, addend=False):
+    from keymorph_amd import _lib
+    return _lib.load().kmh_conv3d_fwd_bf_variant(N, D, H, W, Cin, Cout, 2, int(mask), int(addend))
+
+
+def test_fp64_restatement_is_conv3d():
+    g = gen(0)
+    x = torch.randn(2, 5, 4, 6, 7, generator=g, dtype=torch.float64)
+    w = torch.randn(6, 5, 3, 3, 3, generator=g, dtype=torch.float64)
+    ref = F.conv3d(x, w, None, padding=1).permute(0, 2, 3, 4, 1)
+    assert rel(conv3_fp64(x.permute(0, 2, 3, 4, 1).contiguous(), w), ref) < 1e-14
+    gam, bet = torch.randn(5, generator=g, dtype=torch.float64), torch.randn(5, generator=g, dtype=torch.float64)
+    refn = F.group_norm(x, 1, gam, bet, 1e-5).permute(0, 2, 3, 4, 1)
+    assert rel(group_norm_fp64(x.permute(0, 2, 3, 4, 1).contiguous(), 1, gam, bet), refn) < 1e-13
+
+
+def test_dispatch_setter_and_variant_query(dispatch):
+    from keymorph_amd import _lib
+    lib = _lib.load()
+    assert lib.kmh_conv3d_fwd_bf_set_dispatch(7) == -22 and lib.kmh_conv3d_fwd_bf_set_dispatch(-1) == -22
+    dispatch(1)
+    assert variant(1, 30, 61, 121, 64, 64) == 0            # 4 * 8 * 8 = 256 bricks of one channel group: below 512
+    assert variant(4, 128, 128, 128, 64, 64) == 2 and variant(4, 256, 256, 256, 16, 32) == 1
+    assert variant(4, 256, 256, 256, 32, 16) == 3
+    dispatch(2)
+    assert variant(1, 5, 7, 9, 16, 32) == 1 and variant(1, 5, 7, 9, 32, 16) == 3 and variant(1, 5, 7, 9, 48, 96) == 2
+    assert variant(1, 5, 7, 9, 16, 32, mask=True) == 0      # a fused ReLU-mask operand belongs to conv3_fwd_bf_kernel
+    assert variant(1, 5, 7, 9, 12, 32) == 0                 # whole 8-channel chunks only
+    assert variant(1, 5, 7, 9, 32, 16, addend=True) == 0
+    dispatch(0)
+    assert variant(4, 128, 128, 128, 64, 64) == 0
+
+
+# (N, (D, H, W), Cin, Cout): volumes that are multiples of NEITHER the 32x8x4 brick NOR the 8x8 brick patch, several
+# samples in one work list.  (45,60,100): tiles (4, 8 of which the last is half, 12 of which the last holds 1 plane);
+# (30,61,121): one x column of the last brick, a 5-row y brick, a 2-plane z brick; (130, 20, 33): 33 z bricks -> 5
+# patches of 8 with one brick in the last, one voxel in the last x brick; (9, 243, 40): tiles_y = 31 -> 4 patches.
+RAGGED = [
+    (2, (45, 60, 100), 16, 32),       # g<1,false>: the 256^3 level's forward shape (16 -> 32)
+    (2, (45, 60, 100), 32, 16),       # g<1,true>: its z-paired data gradient (32 -> 16)
+    (2, (30, 61, 121), 64, 64),       # g<2,false>
+    (3, (30, 61, 121), 48, 96),       # g<2,false>, two 64-wide channel groups, the second half empty; N = 3
+    (2, (130, 20, 33), 32, 32),
+    (1, (9, 243, 40), 24, 8),         # z-paired with Cout = 8
+    (2, (7, 9, 31), 128, 72),         # 16 chunks, tiny volume: every brick partial
+]
+
+
+@pytest.mark.parametrize("cfg", RAGGED)
+def test_forward_kernel_g_ragged_vs_fp64_and_bit_identical(cfg, dispatch):
+    """relu(conv3(x * scale + shift)) with output statistics, through the C ABI entry the backbone uses
+    (kmh_conv3d_fwd_bf via backbone_ops.conv3_raw): conv3_fwd_g_kernel forced == conv3_fwd_bf_kernel bit for bit, and
+    both within 3e-6 of the tensor maximum of the fp64 result (the bar of test_conv_arithmetic_modes_vs_fp64)."""
+    from keymorph_amd import backbone_ops as B
+    N, dims, Cin, Cout = cfg
+    D, H, W = dims
+    old = B.CONV_MODE
+    try:
+        B.set_conv_mode("f16x3")
+        g = gen(100 + Cin + Cout)
+        x = (torch.randn(N, D, H, W, Cin, generator=g).abs() + 0.1 * torch.randn(N, D, H, W, Cin, generator=g)).to(DEV)
+        scale = (1 + 0.3 * torch.randn(N, Cin, generator=g)).to(DEV)
+        shift = (0.3 * torch.randn(N, Cin, generator=g)).to(DEV)
+        w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / np.sqrt(27 * Cin)).to(DEV)
+        xn64 = x.double() * scale.double()[:, None, None, None, :] + shift.double()[:, None, None, None, :]
+        ref = torch.relu(conv3_fp64(xn64, w.double()))
+        ascale = B.absmax_scale(xn64.float())        # any bound of the normalised tensor's magnitude will do
+        out = {}
+        for mode in (0, 2):
+            dispatch(mode)
+            v = variant(N, D, H, W, Cin, Cout)
+            assert (v == 0) if mode == 0 else (v == (3 if Cout <= 16 else 2 if Cout > 32 else 1)), (mode, v)
+            pk = B.pack_weight(w, False)
+            st = torch.full((N, Cout, 2), float("nan"), dtype=torch.float64, device=DEV)
+            y = B.conv3_raw(x, scale, shift, pk, None, N, D, H, W, Cin, Cout, False, True, ascale=ascale, stats_out=st)
+            torch.cuda.synchronize()
+            out[mode] = (y, st)
+            assert rel(y, ref) < 3e-6, (mode, G_KERNEL.get(v), rel(y, ref))
+            st_ref = torch.stack([ref.sum(dim=(1, 2, 3)), (ref * ref).sum(dim=(1, 2, 3))], dim=-1)
+            assert rel(st, st_ref) < 2e-6, (mode, rel(st, st_ref))
+        assert torch.equal(out[0][0], out[2][0]), "conv3_fwd_g_kernel is not bit-identical to conv3_fwd_bf_kernel"
+        # the statistics are sums of the same values in a different order (bricks of another height)
+        assert rel(out[2][1], out[0][1]) < 1e-6
+    finally:
+        B.set_conv_mode(old)
+
+
+@pytest.mark.parametrize("cfg", RAGGED)
+@pytest.mark.parametrize("blocked", [False, True])
+def test_data_gradient_kernel_g_ragged_vs_fp64_and_bit_identical(cfg, blocked, dispatch):
+    """the data gradient = the same kernel on tap-mirrored weights, no normalisation, no activation, premasked
+    gradient (no mask operand), with the (sum dxn) statistics of its epilogue; optionally reading a channel-blocked
+    gradient (N, C/8, D, H, W, 8) as the hand-off inside a DoubleConv does."""
+    from keymorph_amd import backbone_ops as B
+    N, dims, Cw_in, Cw_out = cfg           # the forward layer is Cw_in -> Cw_out; the data gradient maps Cw_out -> Cw_in
+    D, H, W = dims
+    if Cw_out % 8 or Cw_in % 4:
+        pytest.skip("the LDS-DMA kernel needs whole 8-channel input chunks")
+    old = B.CONV_MODE
+    try:
+        B.set_conv_mode("f16x3")
+        g = gen(200 + Cw_in + Cw_out)
+        dz = torch.randn(N, D, H, W, Cw_out, generator=g)
+        dz = (dz * (torch.rand(N, D, H, W, Cw_out, generator=g) > 0.4) * 3e-4).to(DEV)        # masked, small magnitudes
+        w = (torch.randn(Cw_out, Cw_in, 3, 3, 3, generator=g) / np.sqrt(27 * Cw_in)).to(DEV)
+        # dxn[v, ci] = sum_{tap, co} dz[v - tap, co] W[co, ci, tap]: correlation with the mirrored, transposed filter
+        wt = w.double().flip(2, 3, 4).permute(1, 0, 2, 3, 4).contiguous()
+        ref = conv3_fp64(dz.double(), wt)
+        dscale = B.absmax_scale(dz)
+        dz_in = dz
+        if blocked:
+            dz_in = dz.view(N, D, H, W, Cw_out // 8, 8).permute(0, 4, 1, 2, 3, 5).contiguous()
+        out = {}
+        for mode in (0, 2):
+            dispatch(mode)
+            v = variant(N, D, H, W, Cw_out, Cw_in)
+            assert (v == 0) if mode == 0 else (v == (3 if Cw_in <= 16 else 2 if Cw_in > 32 else 1)), (mode, v)
+            pk = B.pack_weight(w, True)
+            st = torch.full((N, Cw_in, 2), float("nan"), dtype=torch.float64, device=DEV)
+            y = B.conv3_raw(dz_in, None, None, pk, None, N, D, H, W, Cw_out, Cw_in, False, False, ascale=dscale,
+                            stats_out=st, in_blocked=blocked)
+            torch.cuda.synchronize()
+            out[mode] = (y, st)
+            assert rel(y, ref) < 3e-6, (mode, G_KERNEL.get(v), rel(y, ref))
+            # a cancelling sum: its error is measured against sum |dxn|
+            err = float((st[..., 0] - ref.sum(dim=(1, 2, 3))).abs().max()) / float(ref.abs().sum(dim=(1, 2, 3)).max())
+            assert err < 1e-6, (mode, err)
+        assert torch.equal(out[0][0], out[2][0])
+    finally:
+        B.set_conv_mode(old)
+
+
+@pytest.mark.parametrize("cfg", [(2, (30, 61, 121), 64, 64), (2, (45, 60, 100), 16, 32), (1, (20, 12, 70), 128, 128)])
+def test_forward_kernel_g_addend_ragged(cfg, dispatch):
+    """`addend` (the fused decoder operator's low-resolution contribution) is added before the ReLU and the statistics"""
+    from keymorph_amd import backbone_ops as B
+    N, dims, Cin, Cout = cfg
+    D, H, W = dims
+    old = B.CONV_MODE
+    try:
+        B.set_conv_mode("f16x3")
+        g = gen(300 + Cin)
+        x = torch.randn(N, D, H, W, Cin, generator=g).to(DEV)
+        add = torch.randn(N, D, H, W, Cout, generator=g).to(DEV)
+        w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / np.sqrt(27 * Cin)).to(DEV)
+        ref = torch.relu(conv3_fp64(x.double(), w.double()) + add.double())
+        out = {}
+        for mode in (0, 2):
+            dispatch(mode)
+            assert (variant(N, D, H, W, Cin, Cout, addend=True) != 0) == (mode == 2)
+            st = torch.empty((N, Cout, 2), dtype=torch.float64, device=DEV)
+            y = B.conv3_raw(x, None, None, B.pack_weight(w, False), None, N, D, H, W, Cin, Cout, False, True,
+                            stats_out=st, addend=add)
+            out[mode] = y
+            assert rel(y, ref) < 3e-6
+            assert rel(st[..., 1], (ref * ref).sum(dim=(1, 2, 3))) < 2e-6
+        assert torch.equal(out[0], out[2])
+    finally:
+        B.set_conv_mode(old)
+
+
+@pytest.mark.parametrize("cfg", [(2, (45, 60, 100), 16, 32, 8), (2, (30, 61, 121), 64, 64, 8), (3, (21, 37, 50), 48, 96, 8),
+                                 (2, (45, 60, 100), 32, 16, 8)])
+def test_single_conv_layer_ragged_forced_kernel_g_all_gradients_vs_fp64(cfg, dispatch):
+    """One whole SingleConv (GroupNorm -> conv -> ReLU), forward and every gradient, with the LDS-DMA kernel forced in
+    both directions and the wave-specialised weight gradient (conv3_wgrad_ws_kernel) on the same ragged multi-sample
+    volume, against fp64 autograd of the same expression.  The cotangent is premasked by (y > 0), as a downstream
+    SingleConv hands it over -- the only case in which the data gradient takes no mask operand."""
+    from keymorph_amd import backbone_ops as B
+    N, dims, Cin, Cout, G = cfg
+    D, H, W = dims
+    old = B.CONV_MODE
+    try:
+        B.set_conv_mode("f16x3")
+        dispatch(2)
+        g = gen(400 + Cin + Cout)
+        x = (torch.randn(N, D, H, W, Cin, generator=g).abs() + 0.1 * torch.randn(N, D, H, W, Cin, generator=g)).to(DEV)
+        gamma = (1 + 0.2 * torch.randn(Cin, generator=g)).to(DEV)
+        beta = (0.2 * torch.randn(Cin, generator=g)).to(DEV)
+        w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / np.sqrt(27 * Cin)).to(DEV)
+        cot = torch.randn(N, D, H, W, Cout, generator=g).to(DEV)
+        Hh = [t.clone().requires_grad_(True) for t in (x, gamma, beta, w)]
+        assert variant(N, D, H, W, Cin, Cout) != 0 and variant(N, D, H, W, Cout, Cin) != 0
+        yh = B.single_conv_gcr(*Hh, G, x_from_relu=False, dy_premasked=True)
+        # the cotangent is masked with OUR sign pattern (what a downstream layer hands over) and the fp64 reference
+        # differentiates the pre-activation against the same masked cotangent, so that a sign flip of a |y| ~ 1e-7
+        # output cannot enter the comparison
+        cotm = cot * (yh.detach() > 0)
+        (yh * cotm).sum().backward()
+        R = [t.double().clone().requires_grad_(True) for t in (x, gamma, beta, w)]
+        pre = conv3_fp64(group_norm_fp64(R[0], G, R[1], R[2]), R[3])
+        (pre * cotm.double()).sum().backward()
+        assert rel(yh, torch.relu(pre.detach())) < 3e-6
+        assert rel(Hh[0].grad, R[0].grad) < 5e-6
+        assert rel(Hh[3].grad, R[3].grad) < 3e-6
+        assert rel(Hh[1].grad, R[1].grad) < 2e-5 and rel(Hh[2].grad, R[2].grad) < 2e-5
+    finally:
+        B.set_conv_mode(old)
