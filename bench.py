@@ -52,6 +52,18 @@ def parse():
     ap.add_argument("--dice", type=int, default=1,
                     help="N > 0: also time N steps of the Dice branch (scripts/train.py:146-164: a 14-class one-hot "
                          "segmentation warped with the same grid + DiceLoss as the loss) -> dice_pairs_per_s")
+    ap.add_argument("--eval-steps", type=int, default=3,
+                    help="N > 0: also time N evaluation passes (scripts/pairwise_register_eval.py:116-171: model.eval(), "
+                         "no_grad, a list of transform types, aligned points, align_img per type) -> eval_pairs_per_s")
+    ap.add_argument("--groupwise", type=int, default=8,
+                    help="S > 0: also time KeyMorph.groupwise_register over S synthetic subjects at --size (BASELINE "
+                         "configs[4]: 8 subjects, 512 keypoints, TPS, num_iters 5) -> groupwise_subjects_per_s")
+    ap.add_argument("--convnet", type=int, default=1,
+                    help="N > 0: also time N training steps with the ConvNet(instance norm) backbone (keymorph/net.py:7-36)")
+    ap.add_argument("--sampler", type=int, default=1, help="report stand-alone align_img GB/s for C = 1 and C = 14")
+    ap.add_argument("--cpu-256", type=int, default=1,
+                    help="1: also time the oracle ONCE at the metric's shape (size^3, 512 keypoints, affine, fwd+bwd; "
+                         "~1 min, ~50 GB of host RAM; skipped when less than 96 GB is available)")
     return ap.parse_args()
 
 
@@ -136,7 +148,7 @@ def roofline(mode, conv_tf):
             "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": src}
 
 
-def cpu_baseline(threads, seconds):
+def cpu_baseline(threads, seconds, big_size=0, big_kp=512):
     """BASELINE.json configs[0] measured, not extrapolated: the oracle (CPU restatement, same ATen ops as the
     reference; pinned against the reference's own outputs for exactly this pair, tests/test_cfg1_gpu.py) on the host
     cores -- the example_data_half pair at 128^3 (intensity = label / 13; tests/golden/
@@ -175,6 +187,35 @@ def cpu_baseline(threads, seconds):
         step()
         n += 1
     dt = (time.time() - t0) / n
+    big = None
+    if big_size:
+        avail = 0.0
+        try:
+            for line in open("/proc/meminfo"):
+                if line.startswith("MemAvailable"):
+                    avail = float(line.split()[1]) / 2 ** 20
+        except OSError:
+            pass
+        if avail >= 96:
+            # BASELINE configs[1] shape on the host: the same synthetic pair recipe as the GPU legs (blob volume and an
+            # affine-warped copy, generated on the CPU by the oracle), 512 keypoints, affine aligner, fwd + bwd, MSE;
+            # ONE pair, no warm-up (the process is warm from the 128^3 sample; a pair is tens of seconds)
+            from keymorph_amd import synthetic
+            cpu_dev = torch.device("cpu")
+            fb = synthetic.blob_volume(big_size, 100, cpu_dev)
+            gridb = O.affine_grid(torch.inverse(synthetic.random_affine_matrix(100, cpu_dev)), (big_size,) * 3)
+            mb = O.align_img(gridb, fb)
+            del gridb
+            sdb = {k: v.requires_grad_(True) for k, v in seeded_state_dict(unet_shapes(big_kp, 32, trunc=1), 23).items()}
+            tb = time.time()
+            rb = O.keymorph_forward(lambda x: O.unet3d_forward(sdb, x, 4, 1, 8), fb, mb, "affine")
+            t_fwd = time.time() - tb
+            O.mse_loss(fb, O.align_img(rb["grid"], mb)).backward()
+            big = {"seconds_per_pair": time.time() - tb, "forward_seconds": t_fwd, "size": big_size, "keypoints": big_kp,
+                   "mem_available_gib": avail}
+            del rb, sdb, fb, mb
+        else:
+            big = {"skipped": f"only {avail:.0f} GiB of host RAM available (needs ~50, wants 96)"}
     cpu = platform.processor() or ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -185,7 +226,8 @@ def cpu_baseline(threads, seconds):
         pass
     print("# cpu_baseline: %d of %d host cores, %s\n# %s" % (nthreads, ncores, cpu, torch.__config__.show().replace("\n", "\n# ")),
           file=sys.stderr)
-    return {"seconds_per_pair": dt, "pairs": n, "threads": nthreads, "host_cores": ncores, "cpu_model": cpu, "data": data}
+    return {"seconds_per_pair": dt, "pairs": n, "threads": nthreads, "host_cores": ncores, "cpu_model": cpu, "data": data,
+            "big": big}
 
 
 def main():
@@ -261,6 +303,131 @@ def main():
         extra.update({"f32_mfma_ms_per_step": 1000 * dt_f, "f32_mfma_pairs_per_s": a.pairs_per_gpu * world / dt_f,
                       "f32_mfma_note": f"same step with KEYMORPH_HIP_CONV=f32 (v_mfma_f32_32x32x2_f32, no operand "
                                        f"splitting), {a.also_f32} timed step(s)"})
+    def side_leg(name, fn):
+        """the side figures must never cost the headline line: a failure is reported under `<name>_error`"""
+        try:
+            fn()
+        except Exception as e:      # noqa: BLE001
+            extra[name + "_error"] = f"{type(e).__name__}: {e}"[:300]
+        torch.cuda.empty_cache()
+
+    def eval_leg():
+        # scripts/pairwise_register_eval.py:116-171 / scripts/register.py:264-275: model.eval(), no_grad, one backbone
+        # pass, every transform type of the list fitted and evaluated, aligned points, the moving image warped per type
+        from keymorph_amd import utils
+        types = ["rigid", "affine", "tps_10", "tps_0"]
+        model.eval()
+
+        def one():
+            with torch.no_grad():
+                res = model(img_f, img_m, transform_type=types, return_aligned_points=True)
+                return [utils.align_img(res[t]["grid"], img_m) for t in types]
+        try:
+            one()
+            sync()
+            t = time.perf_counter()
+            for _ in range(a.eval_steps):
+                one()
+            sync()
+            t = (time.perf_counter() - t) / a.eval_steps
+        finally:
+            model.train()
+        if world > 1:
+            tt_ = torch.tensor([t], device=dev)
+            torch.distributed.all_reduce(tt_, op=torch.distributed.ReduceOp.MAX)
+            t = float(tt_.item())
+        extra.update({"eval_pairs_per_s": a.pairs_per_gpu * world / t, "eval_ms_per_pass": 1000 * t,
+                      "eval_config": f"model.eval(), no_grad, bs={a.pairs_per_gpu} pair(s)/GPU, transform types {types} from "
+                                     f"ONE keypoint extraction, aligned points + align_img per type, {a.eval_steps} timed pass(es)"})
+
+    def groupwise_leg():
+        # BASELINE configs[4]: KeyMorph.groupwise_register (keymorph/model.py:295-530) over S subjects at full size,
+        # TPS, num_iters 5; under N > 1 the subjects are sharded over the ranks (one all-gather of the keypoints)
+        from keymorph_amd.transformations import AffineTransform
+        from keymorph_amd.utils import align_img
+        S, iters, gtype = a.groupwise, 5, "tps_0" if tt.startswith("tps") else tt
+        base = synthetic.blob_volume(a.size, 7, dev)
+        with torch.no_grad():
+            stack = torch.cat([align_img(AffineTransform(matrix=synthetic.random_affine_matrix(40 + i, dev, scale=0.1,
+                                                                                               shift=0.1, rot=0.2, shear=0.05),
+                                                         dim=3).get_flow_field(base.shape), base) for i in range(S)])
+        model.eval()
+
+        def one():
+            with torch.no_grad():
+                return model.groupwise_register(stack, transform_type=[gtype], device=dev, num_iters=iters,
+                                                save_results_to_disk=False)
+        try:
+            r = one()
+            sync()
+            t = time.perf_counter()
+            r = one()
+            sync()
+            t = time.perf_counter() - t
+        finally:
+            model.train()
+        if world > 1:
+            tt_ = torch.tensor([t], device=dev)
+            torch.distributed.all_reduce(tt_, op=torch.distributed.ReduceOp.MAX)
+            t = float(tt_.item())
+        ok = bool(torch.isfinite(r[gtype]["grouppoints_a"]).all())
+        extra.update({"groupwise_subjects_per_s": S / t, "groupwise_ms": 1000 * t, "groupwise_finite": ok,
+                      "groupwise_config": f"BASELINE configs[4]: {S} subjects x {a.size}^3, {a.keypoints} keypoints, {gtype}, "
+                                          f"num_iters {iters}, eval / no_grad, grids kept in HBM; subjects sharded over "
+                                          f"{world} rank(s), one all-gather of the keypoints"})
+
+    def sampler_leg():
+        # stand-alone align_img (keymorph/utils.py:14-21) at the metric's volume size: forward 20 B/voxel for C = 1
+        # (grid 12 + volume 4 + out 4), 12 + 8 C in general; C = 14 is the one-hot segmentation of the Dice branch
+        from keymorph_amd import utils
+        from keymorph_amd.transformations import AffineTransform
+        grid = AffineTransform(matrix=synthetic.random_affine_matrix(3, dev), dim=3).get_flow_field(img_f[:1].shape)
+        out = {}
+        for C in (1, 14):
+            vol = torch.rand(1, C, a.size, a.size, a.size, device=dev)
+            with torch.no_grad():
+                utils.align_img(grid, vol)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    utils.align_img(grid, vol)
+                e1.record()
+                torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            gb = a.size ** 3 * (12 + 8 * C) / 1e9
+            out[f"C{C}"] = {"ms": ms, "algorithmic_GB": gb, "GBps": gb / ms * 1e3, "frac_of_hbm_peak": gb / ms * 1e3 / HBM_PEAK_GBS}
+            del vol
+        extra["align_img_standalone"] = out
+
+    def convnet_leg():
+        # the reference's other backbone (keymorph/net.py:7-36, instance norm): same step, same sizes
+        from keymorph_amd.model import KeyMorph
+        from keymorph_amd.net import ConvNet
+        torch.manual_seed(23)
+        cm = KeyMorph(ConvNet(3, 1, a.keypoints, "instance"), a.keypoints, 3, max_train_keypoints=None).to(dev).train()
+        cflat = parallel.FlatParams(cm.parameters())
+        copt = parallel.FusedAdam(cflat, lr=3e-6)
+        train_step(cm, cflat, copt, img_f, img_m, tt)
+        sync()
+        t = time.perf_counter()
+        for _ in range(a.convnet):
+            lo = train_step(cm, cflat, copt, img_f, img_m, tt)
+        sync()
+        t = (time.perf_counter() - t) / a.convnet
+        extra.update({"convnet_pairs_per_s": a.pairs_per_gpu * world / t, "convnet_ms_per_step": 1000 * t,
+                      "convnet_loss": float(lo.item()),
+                      "convnet_config": f"ConvNet(instance norm, 9 blocks, {a.keypoints} keypoints) backbone, same step and "
+                                        f"sizes as the headline, {a.convnet} timed step(s)"})
+
+    if a.eval_steps > 0:
+        side_leg("eval", eval_leg)
+    if a.groupwise > 0:
+        side_leg("groupwise", groupwise_leg)
+    if a.sampler > 0 and rank == 0:
+        side_leg("align_img_standalone", sampler_leg)
+    if a.convnet > 0 and world == 1:
+        side_leg("convnet", convnet_leg)
     rccl_ranks = 1
     if world > 1:           # an actual collective over the process group the gradients use
         probe = torch.ones(1, device=dev)
@@ -339,22 +506,35 @@ def main():
         }
         out.update(extra)
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
-            c = cpu_baseline(a.cpu_threads, a.cpu_seconds)
+            c = cpu_baseline(a.cpu_threads, a.cpu_seconds, a.size if a.cpu_256 else 0, a.keypoints)
             vox_ratio = (a.size / 128) ** 3
+            big = c.get("big") or {}
+            measured = "seconds_per_pair" in big
+            # `value` is in the headline's units AT the headline's volume size and keypoint count: the measured
+            # size^3 / 512-keypoint pair when the host could run it, else the 128^3 sample scaled by the voxel ratio
+            value = 1.0 / big["seconds_per_pair"] if measured else 1.0 / (c["seconds_per_pair"] * vox_ratio)
             out["cpu_baseline"] = {
-                "value": 1.0 / c["seconds_per_pair"],
+                "value": value,
                 "unit": "pairs/s",
                 "cores": c["threads"],
                 "host_cores_available": c["host_cores"],
                 "cpu_model": c["cpu_model"],
                 "kind": "port",
-                "config": "BASELINE configs[0]: 128^3 pair, 128 keypoints, affine, TruncatedUNet3D(f_maps 32), fwd+bwd, MSE",
-                "sample": f"oracle (torch CPU restatement) on {c['data']}: {c['pairs']} timed pairs at "
-                          f"{c['seconds_per_pair']:.2f} s/pair after one warm-up; measured, not scaled; {c['threads']} "
-                          f"threads = the fastest of a sweep on this host type (256 threads: 73.7 s/pair)",
-                "extrapolated_256_pairs_per_s": 1.0 / (c["seconds_per_pair"] * vox_ratio),
-                "extrapolation": f"value / {vox_ratio:.0f} (voxel ratio to {a.size}^3; optimistic for the CPU: 512-keypoint "
-                                 f"TPS costs more than the affine fit, SURVEY section 6)",
+                "comparable_to_headline": "same volume size and keypoint count, AFFINE aligner (512-keypoint TPS in "
+                                          "training mode cannot run on the reference CPU path: 103 GB temporaries, "
+                                          "BASELINE.md section 2; its chunked TPS costs more, so this flatters the CPU)",
+                "sample": (f"oracle (torch CPU restatement) at BASELINE configs[1] shape: ONE {big.get('size')}^3 synthetic pair, "
+                           f"{big.get('keypoints')} keypoints, affine, fwd+bwd, MSE: {big.get('seconds_per_pair', 0):.1f} s "
+                           f"(forward {big.get('forward_seconds', 0):.1f} s), measured, not scaled; {c['threads']} threads"
+                           if measured else
+                           f"oracle at BASELINE configs[0] (128^3, 128 keypoints, affine) scaled by the voxel ratio "
+                           f"{vox_ratio:.0f}: {big.get('skipped', 'the full-size sample was not requested')}"),
+                "measured_cfg0_pairs_per_s": 1.0 / c["seconds_per_pair"],
+                "measured_cfg0_sample": f"BASELINE configs[0]: 128^3 pair ({c['data']}), 128 keypoints, affine, "
+                                        f"TruncatedUNet3D(f_maps 32), fwd+bwd, MSE: {c['pairs']} timed pairs at "
+                                        f"{c['seconds_per_pair']:.2f} s/pair after one warm-up; {c['threads']} threads = the "
+                                        f"fastest of a sweep on this host type (256 threads: 73.7 s/pair)",
+                "cfg0_scaled_to_headline_size_pairs_per_s": 1.0 / (c["seconds_per_pair"] * vox_ratio),
             }
         print(json.dumps(out))
     if world > 1:

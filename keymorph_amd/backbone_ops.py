@@ -467,10 +467,11 @@ def _up2_forward(skip, low, scale, shift, ascale, weight, N, D, H, W, Cs, Cl, Co
 
 def upcat_conv_ok(skip, low, Cout) -> bool:
     """May relu(conv3(group_norm(cat(skip, up2(low))))) run as the fused operator (no concatenated tensor, the
-    upsampled channels handled at low resolution, forward and backward)?"""
+    upsampled channels handled at low resolution, forward and backward)?  Also under no_grad: the evaluation scripts
+    (scripts/register.py, pairwise_register_eval.py:116-171) run the same forward."""
     return (CONV_MODE in _TERMS and conv_emits_stats() and Cout > 16 and Cout % 4 == 0 and skip.shape[-1] % 8 == 0
             and low.shape[-1] % 8 == 0 and all(a == 2 * b for a, b in zip(skip.shape[1:4], low.shape[1:4]))
-            and torch.is_grad_enabled() and not os.environ.get("KEYMORPH_NO_UPCONV")
+            and not os.environ.get("KEYMORPH_NO_UPCONV")
             and not os.environ.get("KEYMORPH_NO_UPCONV_BWD"))
 
 

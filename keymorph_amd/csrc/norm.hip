@@ -764,7 +764,11 @@ KMH_API int kmh_maxpool3d_bwd(const float* x, const unsigned char* argmax, const
   if ((add && add_cstride < C) || (!x && !argmax)) return -22;
   if (out_blocked && ((C & 7) || (D & 1) || (H & 1) || (W & 1) || add == dx)) return -22;   // whole chunks, every voxel written
   const long long pooled = (long long)Do * Ho * Wo * C;
-  if (argmax && (C & 3) == 0 && (add_cstride & 3) == 0 && pooled / 4 < (1ll << 31) && (long long)D * H * W < (1ll << 31)) {
+  // the 16-byte kernel reads add / dy and writes dx as float4 and the winners as 4 packed bytes: a channel-slice view
+  // whose storage offset is not a multiple of 4 floats takes the scalar kernel
+  const bool aligned = (((uintptr_t)add | (uintptr_t)dx | (uintptr_t)dy) & 15) == 0 && ((uintptr_t)argmax & 3) == 0;
+  if (argmax && aligned && (C & 3) == 0 && (add_cstride & 3) == 0 && pooled / 4 < (1ll << 31) &&
+      (long long)D * H * W < (1ll << 31)) {
     auto kern = out_blocked ? maxpool_bwd4_kernel<true> : maxpool_bwd4_kernel<false>;
     kern<<<dim3(stream_blocks(pooled), N), TPB, 0, (hipStream_t)stream>>>((const unsigned*)argmax, (const float4*)dy, add,
                                                                          add_cstride, dx, D, H, W, C / 4, Do, Ho, Wo);

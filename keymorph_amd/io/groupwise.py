@@ -36,10 +36,13 @@ def evaluate_group(registration_model, group_dir, transform_types, device, metri
     with torch.no_grad():
         results = registration_model.groupwise_register(img_dir, transform_type=list(transform_types), device=device,
                                                         save_results_to_disk=True, save_dir=res_dir, plot=False,
-                                                        num_iters=num_iters, log_to_console=False)
+                                                        num_iters=num_iters, log_to_console=False,
+                                                        shard_subjects=False)   # every rank needs every grid below
     out = {}
     for tt, res in results.items():
-        grids = sorted(os.path.join(res_dir, f) for f in os.listdir(res_dir) if f.startswith(tt))
+        # exact prefix: "tps_0" must not pick up the grids of "tps_0.1"
+        grids = sorted(os.path.join(res_dir, f) for f in os.listdir(res_dir) if f.startswith(f"{tt}_grid_"))
+        assert len(grids) == len(img_paths), (tt, len(grids), len(img_paths))
         img_a_dir, seg_a_dir = os.path.join(group_dir, f"img_a_{tt}"), os.path.join(group_dir, f"seg_a_{tt}")
         os.makedirs(img_a_dir, exist_ok=True)
         os.makedirs(seg_a_dir, exist_ok=True)

@@ -113,8 +113,17 @@ class TPS(nn.Module):
             self.aff_f, self.aff_m = aff_f, aff_m
             self.points_m = convert_points_norm2real(self.points_m, aff_m, shape_m)
             self.points_f = convert_points_norm2real(self.points_f, aff_f, shape_f)
-        self.inverse_theta = self.fit(self.points_f, self.points_m, lmbda, weights=w)
+        # both directions are fitted on first use and cached: the groupwise iterations (model.py:331-444) only ever
+        # need the forward map, a registration without aligned points only the inverse one
+        self._inverse_theta = None
         self.theta = None
+
+    @property
+    def inverse_theta(self):
+        """theta of the fixed -> moving map the sampling grid needs (keypoint_aligners.py:274)"""
+        if self._inverse_theta is None:
+            self._inverse_theta = self.fit(self.points_f, self.points_m, self.lmbda, weights=self.weights)
+        return self._inverse_theta
 
     @staticmethod
     def _lmbda_vec(lmbda, n, device):

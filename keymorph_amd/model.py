@@ -248,14 +248,15 @@ class KeyMorph(nn.Module):
 
             curr_points = group_points.clone()
             mean_points = curr_points.mean(dim=0, keepdim=True)
+            n_sub = len(curr_points)
+            lm_all = None if tps_lmbda is None else tps_lmbda.reshape(-1)[:1].expand(n_sub).contiguous()
             for j in range(num_iters):
+                # model.py:331-444 loops over the subjects; the aligners are batched (row i == the bs = 1 result for
+                # subject i), so one fit launch solves all subjects' systems side by side, one CU each
                 mean_points = curr_points.mean(dim=0, keepdim=True)
-                nxt = torch.zeros_like(curr_points)
-                for i in range(len(curr_points)):
-                    pm = curr_points[i:i + 1]
-                    al = self._make_aligner_plain(align_type, pm, mean_points, tps_lmbda)
-                    nxt[i:i + 1] = al.get_forward_transformed_points(pm)
-                curr_points = nxt
+                al = self._make_aligner_plain(align_type, curr_points, mean_points.expand_as(curr_points).contiguous(),
+                                              lm_all)
+                curr_points = al.get_forward_transformed_points(curr_points)
                 log(f"-> Iteration {j + 1}/{num_iters}")
             res = {"time": time.time() - start_time, "grouppoints_m": group_points, "grouppoints_a": curr_points}
 

@@ -139,7 +139,9 @@ class _WarpMSE(torch.autograd.Function):
                 _lib.profiler.meta = {"bytes": float(N * Do * Ho * Wo) * (12 + 12 * C)}
             check(lib.kmh_warp_mse_fwd(_p(x), _p(grid), _p(fixed), _p(out), _p(loss), N, C, D, H, W, Do, Ho, Wo,
                                        _p(_reduce_ws(x.device)), _stream()), "kmh_warp_mse_fwd")
-            ctx.save_for_backward(x, grid, fixed, out)
+        # always saved (inputs and the returned output: no extra memory): the plain three-launch backward serves a
+        # grid that needed the non-fused route and every backward after the first one
+        ctx.save_for_backward(x, grid, fixed, out)
         ctx.mark_non_differentiable(out)
         return loss, out
 
@@ -147,6 +149,9 @@ class _WarpMSE(torch.autograd.Function):
     def backward(ctx, gloss, _gout):
         lib = _lib.load()
         if ctx.dgrid is not None:
+            # d(loss)/d(grid) was written by the forward pass: the first backward hands that buffer out, scaled in place
+            # by the cotangent (a device-side check makes the usual cotangent 1 a no-op: no pass over 200 MB, no host
+            # synchronisation).  A second backward over a retained graph recomputes it from the saved tensors below.
             dgrid, ctx.dgrid = ctx.dgrid, None
             gl = _prep(gloss).reshape(1)
             check(lib.kmh_scale_unless_one(_p(dgrid), dgrid.numel(), _p(gl), _stream()), "kmh_scale_unless_one")

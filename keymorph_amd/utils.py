@@ -57,6 +57,11 @@ def _seg_on_gpu(seg):
     returned there (the later ``.float().to(device)`` is then a no-op)."""
     if not seg.is_cuda:
         seg = seg.to(torch.device("cuda", torch.cuda.current_device()))
+    elif seg.device.index != torch.cuda.current_device():
+        # same rule as ops._prep: the C ABI launches on the current device's stream and never calls hipSetDevice
+        from ._lib import KeymorphHipError
+        raise KeymorphHipError(f"label map is on {seg.device} but the current device is "
+                               f"cuda:{torch.cuda.current_device()}: call torch.cuda.set_device(...) first")
     if seg.dtype != torch.int64:
         seg = seg.long()
     return seg.contiguous()
@@ -76,17 +81,28 @@ def _labels_present(seg):
 
 
 def _encode(seg, labels, as_int64):
+    """out[n, c] = (seg[n] == labels[c]); any number of channels (the kernel takes 256 labels per launch, so e.g. a
+    FreeSurfer aparc+aseg map with ids up to 2035 is encoded in 8 launches into channel slices of one tensor); no
+    shared label at all gives the reference's empty (N, 0, ...) tensor."""
     from . import _lib
     lib = _lib.load()
-    if len(labels) > 256:
-        raise ValueError("at most 256 one-hot channels")
     n = seg.shape[0]
-    v = seg.numel() // n
+    v = seg.numel() // max(n, 1)
+    C = len(labels)
+    dt = torch.int64 if as_int64 else torch.float32
+    if C == 0 or seg.numel() == 0:
+        return torch.zeros((n, C, *seg.shape[2:]), dtype=dt, device=seg.device)
     lab = torch.as_tensor(np.asarray(labels, dtype=np.int64), device=seg.device)
-    out = torch.empty((n, len(labels), *seg.shape[2:]), dtype=torch.int64 if as_int64 else torch.float32,
-                      device=seg.device)
-    ops.check(lib.kmh_one_hot_select(ops._p(seg), n, v, ops._p(lab), len(labels), ops._p(out), int(as_int64),
-                                     ops._stream()), "kmh_one_hot_select")
+    out = torch.empty((n, C, *seg.shape[2:]), dtype=dt, device=seg.device)
+    if C <= 256:
+        ops.check(lib.kmh_one_hot_select(ops._p(seg), n, v, ops._p(lab), C, ops._p(out), int(as_int64), ops._stream()),
+                  "kmh_one_hot_select")
+        return out
+    for i in range(n):               # channel slices of one sample are contiguous
+        for c0 in range(0, C, 256):
+            c1 = min(C, c0 + 256)
+            ops.check(lib.kmh_one_hot_select(ops._p(seg[i]), 1, v, ops._p(lab[c0:c1]), c1 - c0, ops._p(out[i, c0:c1]),
+                                             int(as_int64), ops._stream()), "kmh_one_hot_select")
     return out
 
 

@@ -1,6 +1,8 @@
 """GPU: size-independent properties at BASELINE.json's full configuration (256^3, 512 keypoints,
 TruncatedUNet3D f_maps=32) -- the oracle cannot run these sizes in seconds, so parity here is through
 invariants the domain offers.  One model / one pair is shared by the whole module."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -232,3 +234,98 @@ def test_two_pairs_per_gpu_equal_two_single_pairs(world):
     lm = 0.5 * (ls[0][0] + ls[1][0])
     assert abs(lb - lm) <= 1e-5 * max(1.0, abs(lm)), (lb, lm)
     assert np.isfinite(lt) and bool(torch.isfinite(grid_t).all())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: groupwise registration of 8 subjects x 256^3, 512 keypoints, TPS
+# (keymorph/model.py:295-530, scripts/groupwise_register_eval.py:379-431), on one GPU, evaluation mode, no_grad.
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_grid_samples(pts_m, mean, tt, idx):
+    """the oracle's final grid of one subject at the lattice points idx = (iz, iy, ix) index tensors (fp32 CPU path):
+    keymorph/model.py:453-510 -> register(points_f = mean, points_m = subject)"""
+    from oracle import keymorph_oracle as O
+    kind, lam = O.parse_transform(tt)
+    g = O.base_grid((SIZE, SIZE, SIZE))[idx[0], idx[1], idx[2]].reshape(1, -1, 3)
+    if kind == "tps":
+        lm = torch.full((1,), lam)
+        out = O.tps_transform_points(O.tps_fit(mean, pts_m, lm), mean, g)
+    else:
+        inv = O.square((O.affine_fit if kind == "affine" else O.rigid_fit)(mean, pts_m))
+        out = O.matrix_transform_points(inv, g)
+    return out.flip(-1)[0]
+
+
+def test_groupwise_8x256(world, tmp_path):
+    from keymorph_amd import synthetic
+    from keymorph_amd.transformations import AffineTransform
+    from keymorph_amd.utils import align_img
+    from oracle import keymorph_oracle as O
+    km = world["km"].eval()
+    dev = torch.device(DEV)
+    n_sub, iters = 8, 5
+    base = synthetic.blob_volume(SIZE, 3, dev)
+    with torch.no_grad():
+        subs = [base] + [align_img(AffineTransform(matrix=synthetic.random_affine_matrix(40 + i, dev, scale=0.1, shift=0.1,
+                                                                                          rot=0.2, shear=0.05),
+                                                   dim=3).get_flow_field(base.shape), base) for i in range(1, n_sub)]
+        stack = torch.cat(subs).contiguous()
+        del subs
+        types = ["affine", "tps_1", "tps_0"]
+        res = km.groupwise_register(stack, transform_type=types, device=dev, num_iters=iters, save_results_to_disk=True,
+                                    save_dir=str(tmp_path), log_to_console=False)
+        solo = torch.cat([km.get_keypoints(stack[i:i + 1]) for i in (0, 3, 7)])
+    pts = res["affine"]["grouppoints_m"]
+    assert pts.shape == (n_sub, K, 3)
+    close(pts[[0, 3, 7]], solo, 2e-6)                 # the stack's keypoints are each subject's own
+    g = torch.Generator().manual_seed(5)
+    idx = tuple(torch.randint(0, SIZE, (4096,), generator=g) for _ in range(3))
+    for tt in types:
+        r = res[tt]
+        assert r["grouppoints_a"].shape == (n_sub, K, 3) and bool(torch.isfinite(r["grouppoints_a"]).all())
+        files = sorted(f for f in os.listdir(tmp_path) if f.startswith(f"{tt}_grid_"))
+        assert files == [f"{tt}_grid_{i:03}.npy" for i in range(n_sub)], files
+        # the iterations against the oracle's (fp32 CPU) on OUR keypoints: model.py:331-444
+        if tt != "tps_0":       # lambda = 0 on the clumped keypoints of a random-init net: conditioning, not arithmetic
+            pa, mean = O.groupwise_points(pts.cpu(), tt, iters)
+            close(r["grouppoints_a"], pa, 1e-4)
+            for i in (0, 5):
+                grid = np.load(os.path.join(tmp_path, files[i]), mmap_mode="r")
+                assert grid.shape == (1, SIZE, SIZE, SIZE, 3) and grid.dtype == np.float32
+                ours = torch.from_numpy(np.ascontiguousarray(grid[0][idx[0].numpy(), idx[1].numpy(), idx[2].numpy()]))
+                close(ours, _oracle_grid_samples(pts[i:i + 1].cpu(), mean, tt, idx), 1e-4)
+        else:
+            grid = np.load(os.path.join(tmp_path, files[2]), mmap_mode="r")
+            assert grid.shape == (1, SIZE, SIZE, SIZE, 3) and bool(np.isfinite(grid[0, ::8, ::8, ::8]).all())
+    # a group of identical subjects: identical keypoints = their own mean, every map the identity
+    from keymorph_amd import ops
+    with torch.no_grad():
+        same = km.groupwise_register(base.expand(3, -1, -1, -1, -1).contiguous(), transform_type=["affine", "tps_1"],
+                                     device=dev, num_iters=2, save_results_to_disk=False)
+    eye = ops.affine_grid(torch.eye(3, 4, device=DEV)[None], (SIZE, SIZE, SIZE))
+    for tt, tol in (("affine", 5e-5), ("tps_1", 1e-4)):
+        close(same[tt]["grouppoints_a"], same[tt]["grouppoints_m"], tol)
+        close(same[tt]["groupgrids"][1, ::37, ::41, ::43], eye[0, ::37, ::41, ::43], tol)
+
+
+def test_eval_path_at_full_size_uses_the_fused_decoder_operator(world, monkeypatch):
+    """scripts/register.py / pairwise_register_eval.py:116-171: model.eval(), no_grad, a list of transform types,
+    return_aligned_points=True.  Under no_grad the decoder must take the same fused upsample+concat+conv operator as
+    the training forward (it was gated on torch.is_grad_enabled() before round 3) and give the same keypoints as the
+    plain upsample + concat + 27-tap route."""
+    from keymorph_amd import backbone_ops as B
+    km = world["km"].eval()
+    before = B.UPCONV_STATS["calls"]
+    with torch.no_grad():
+        res = km(world["img_f"], world["img_m"], transform_type=["rigid", "affine", "tps_10", "tps_0"],
+                 return_aligned_points=True)
+    assert B.UPCONV_STATS["calls"] == before + 2, "the fused decoder operator did not run under no_grad"
+    for tt in ("rigid", "affine", "tps_10", "tps_0"):
+        r = res[tt]
+        assert r["grid"].shape == (1, SIZE, SIZE, SIZE, 3) and bool(torch.isfinite(r["grid"]).all())
+        assert r["points_a"].shape == (1, K, 3)
+    monkeypatch.setenv("KEYMORPH_NO_UPCONV", "1")
+    with torch.no_grad():
+        plain = km.get_keypoints(world["img_f"])
+    assert B.UPCONV_STATS["calls"] == before + 2
+    close(plain, res["affine"]["points_f"], 5e-6)      # (the module's earlier training test moved the weights: compare
+    close(res["tps_0"]["points_f"], res["rigid"]["points_f"], 0)       # within this test, not with world["pts_f"])
