@@ -180,6 +180,16 @@ int kmh_conv3d_fwd_bf_set_dispatch(int mode);
 /* the kernel kmh_conv3d_fwd_bf would launch for this call now: 0 conv3_fwd_bf_kernel, 1 / 2 conv3_fwd_g_kernel with a
  * 32- / 64-wide output-channel tile, 3 its z-paired variant (Cout <= 16) */
 int kmh_conv3d_fwd_bf_variant(int N, int D, int H, int W, int Cin, int Cout, int terms, int has_mask, int has_addend);
+/* GroupNorm -> Conv3d -> ReLU -> MaxPool3d(2) in one launch (keymorph/unet3d/buildingblocks.py:46-78 followed by the next
+ * Encoder's `self.pooling`, :321-380), for a block whose output feeds only that pooling: yp (N, D/2, H/2, W/2, Cout) the
+ * pooled output, arg (same shape, bytes) the winners' window indices in kmh_maxpool3d_fwd's format (ATen's first-max
+ * rule), stats_out (N, Cout, 2) the pooled tensor's (sum, sum^2); the full-resolution output is not written.
+ * kmh_conv3d_fwd_bf_pool_ok: 1 when the shape is served (16 < Cout <= 32, Cin % 8 == 0, terms == 2, LDS-DMA kernel). */
+int kmh_conv3d_fwd_bf_pool_ok(int N, int D, int H, int W, int Cin, int Cout, int terms);
+int kmh_conv3d_fwd_bf_pool(const float* x, const float* scale, const float* shift, const void* packed, float* yp,
+                           unsigned char* arg, int N, int D, int H, int W, int Cin, int Cout, int relu_in, int terms,
+                           const float* ascale, const float* wscale, void* stats_ws, double* stats_out, int in_blocked,
+                           void* stream);
 /* addend (like y) | NULL: added to the result before the activation and the statistics (Cout > 16).
  * Decoder's first convolution without the upsampled tensor: the 27 taps over a nearest-x2 upsampled channel fall on
  * 2 x 2 x 2 low-resolution voxels per output parity, so kmh_conv3d_up2_fwd computes the upsampled channels'

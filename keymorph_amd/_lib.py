@@ -63,6 +63,8 @@ PROTOS = {
     "kmh_conv3d_fwd_bf": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f]),
     "kmh_conv3d_fwd_bf_set_dispatch": (_i, [_i]),
     "kmh_conv3d_fwd_bf_variant": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "kmh_conv3d_fwd_bf_pool_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "kmh_conv3d_fwd_bf_pool": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f]),
     "kmh_conv3d_up2_dgrad_pack_bytes": (_sz, [_i, _i, _i]),
     "kmh_conv3d_up2_dgrad_pack_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f]),
     "kmh_conv3d_up2_dgrad": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),

@@ -121,9 +121,34 @@ def _sum_bound(a: Optional[Tensor], b: Optional[Tensor]) -> Optional[Tensor]:
 
 
 GRAD_SCALE_STATS = {"carried": 0, "measured": 0}
+RANGE_AUDIT_LOG = []          # KEYMORPH_RANGE_AUDIT=1 (debug; synchronises): one record per gradient operand of a backward conv
+
+
+def range_audit(t: Tensor) -> dict:
+    """Debug detector for the ONE range scale an f16x3 gradient operand carries: per sample, how
+    far its largest magnitude lies below the tensor's, and the relative precision its hi + lo fp16 terms keep --
+    max(2^-22, 2^-39 M / m_n): the scaled maximum sits in (2^14, 2^15] and fp16's subnormal quantum is 2^-24, so a
+    sample 2^17 below the maximum still has 22 bits, one 2^30 below 9.  Also the fraction of non-zero elements that
+    flush to zero altogether (|x| S < 2^-25).  Plain torch reductions: a diagnostic, not part of the product path."""
+    with torch.no_grad():
+        a = t.detach().abs().reshape(t.shape[0], -1).float()
+        m_n = a.amax(dim=1).double()
+        M = float(m_n.max())
+        if M == 0.0:
+            return {"max": 0.0, "per_sample_log2_below_max": [0.0] * t.shape[0], "worst_relative_precision": 2.0 ** -22,
+                    "flushed_fraction": 0.0}
+        S = 2.0 ** (14 - int(torch.floor(torch.log2(torch.tensor(M))).item()))       # M * S in [2^14, 2^15)
+        nz = a > 0
+        flushed = float(((a * S < 2.0 ** -25) & nz).sum()) / max(1.0, float(nz.sum()))
+        below = [float(torch.log2(torch.tensor(M) / m)) if float(m) > 0 else float("inf") for m in m_n]
+        prec = max(max(2.0 ** -22, 2.0 ** (b - 39)) for b in below if b != float("inf"))
+        return {"max": M, "per_sample_log2_below_max": below, "worst_relative_precision": prec,
+                "flushed_fraction": flushed}
 
 
 def grad_scale(dy: Tensor) -> Tensor:
+    if os.environ.get("KEYMORPH_RANGE_AUDIT") and not _is_blocked(dy):
+        RANGE_AUDIT_LOG.append(dict(range_audit(dy), shape=tuple(dy.shape)))
     s = _peek_grad_scale(dy)
     if s is not None:
         GRAD_SCALE_STATS["carried"] += 1
@@ -326,9 +351,13 @@ class _SingleConvGCR(torch.autograd.Function):
     """y = relu(conv3(group_norm(x)))  -- all NDHWC."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, weight, num_groups, x_from_relu, dy_premasked, dy_blocked=False, dx_blocked=False):
+    def forward(ctx, x, gamma, beta, weight, num_groups, x_from_relu, dy_premasked, dy_blocked=False, dx_blocked=False,
+                pool=False):
         """dy_blocked: the ONLY consumer of y is a SingleConv called with dx_blocked=True (it returns y's gradient
-        channel-blocked, see grad_blocked_ok); dx_blocked: x is the output of a SingleConv called with dy_blocked=True."""
+        channel-blocked, see grad_blocked_ok); dx_blocked: x is the output of a SingleConv called with dy_blocked=True.
+        pool: return maxpool2(y) instead of y, computed in the convolution's epilogue (conv_pool_ok): y itself is never
+        written; the backward scatters the pooled gradient through the recorded winners (channel-blocked when dy_blocked)
+        and continues as usual."""
         upsrc = _up_sources(x)
         x, gamma, beta, weight = _prep(x), _prep(gamma), _prep(beta), _prep(weight)
         N, D, H, W, Cin = x.shape
@@ -357,11 +386,30 @@ class _SingleConvGCR(torch.autograd.Function):
             skip, low = upsrc
             y = _up2_forward(skip, low, scale, shift, ascale, weight, N, D, H, W, skip.shape[-1], low.shape[-1], Cout,
                              ystats)
+        elif pool:
+            assert dy_premasked and ystats is not None and conv_pool_ok(N, D, H, W, Cin, Cout)
+            lib = _lib.load()
+            pk = pack_weight(weight, False)
+            ctx.wscale = getattr(pk, "_kmh_wscale", None)
+            y = _f32((N, D // 2, H // 2, W // 2, Cout), x.device)
+            arg = torch.empty((N, D // 2, H // 2, W // 2, Cout), dtype=torch.uint8, device=x.device)
+            sws = workspace(int(lib.kmh_conv3d_fwd_bf_stats_ws_bytes(N, D, H, W, Cout, BF_ROWS_PER_WAVE)), x.device,
+                            "convstats")
+            if _lib.profiler.enabled:
+                _lib.profiler.meta = {"flops": 2.0 * 27 * Cin * Cout * N * D * H * W, "shape": (N, D, H, W, Cin, Cout)}
+            check(lib.kmh_conv3d_fwd_bf_pool(_p(x), _p(scale), _p(shift), _p(pk), _p(y), _p(arg), N, D, H, W, Cin, Cout, 0,
+                                             2, _p(ascale), _p(pk._kmh_wscale), _p(sws), _p(ystats), 0, _stream()),
+                  "kmh_conv3d_fwd_bf_pool")
+            ctx.pool_arg = arg
+            POOL_STATS["fused"] += 1
         else:
             pk = pack_weight(weight, False)
             ctx.wscale = getattr(pk, "_kmh_wscale", None)   # the data-gradient packing of the backward re-uses it
             y = conv3_raw(x, scale, shift, pk, None, N, D, H, W, Cin, Cout, False, True, ascale=ascale,
                           stats_out=ystats)
+        ctx.pool = bool(pool)
+        # (pool: y is the POOLED output -- saved only because the slot exists; the backward never reads it, the
+        # gradient it receives being masked already)
         ctx.save_for_backward(x, y, scale, shift, mr, gamma, weight, beta)
         ctx.ascale = ascale               # range scale of the normalised input (f16x3), reused by the weight gradient
         ctx.cfg = (num_groups, bool(x_from_relu), bool(dy_premasked))
@@ -381,12 +429,27 @@ class _SingleConvGCR(torch.autograd.Function):
         Cout = weight.shape[0]
         V = D * H * W
         dy_blocked, dx_blocked = ctx.blocked
-        if _is_blocked(dy) != dy_blocked:        # a lost or unexpected layout tag would silently scramble channels
+        if _is_blocked(dy) != (dy_blocked and not ctx.pool):   # a lost or unexpected layout tag would silently scramble channels
             raise RuntimeError("keymorph_amd: gradient layout mismatch (channel-blocked tag %s, expected %s); something "
                                "between two SingleConvs replaced the gradient tensor (a hook?) -- set "
                                "KEYMORPH_NO_BLOCKED_GRADS=1 to keep every gradient in (N,D,H,W,C)"
                                % (_is_blocked(dy), dy_blocked))
+        sd_in = _peek_grad_scale(dy)
         dy = _prep(dy)
+        if ctx.pool:
+            # the pooled output's gradient -> the full-resolution one through the winners recorded by the epilogue
+            # (the pooling layer's backward, kmh_maxpool3d_bwd), channel-blocked when the gradient kernels take it so
+            full = torch.empty((N, D, H, W, Cout), dtype=torch.float32, device=dy.device)
+            odd = (D | H | W) & 1
+            if odd:
+                full.zero_()
+            check(lib.kmh_maxpool3d_bwd(None, _p(ctx.pool_arg), _p(dy), None, 0, _p(full), N, D, H, W, Cout,
+                                        int(dy_blocked), _stream()), "kmh_maxpool3d_bwd")
+            _tag_grad_scale(full, sd_in)       # scattering moves values: the bound of the pooled gradient holds
+            dy = full
+            if dy_blocked:
+                dy._kmh_blocked = dy._version
+                BLOCKED_STATS["handoffs"] += 1
         # ReLU backward (dz = dy * [y > 0]) is fused into the loaders of both gradient kernels -- and is
         # skipped altogether when every consumer of y already returned a gradient masked by (y > 0)
         # (a downstream SingleConv with x_from_relu, possibly through max-pool / upsample+concat).
@@ -396,7 +459,7 @@ class _SingleConvGCR(torch.autograd.Function):
         if first:
             dw, dgamma, dbeta = first_layer_grads(x, scale, shift, mr, gamma, weight, dy, ymask, N, D, H, W, Cout, G,
                                                   dscale=dscale)
-            return None, dgamma, dbeta, dw, None, None, None, None, None
+            return None, dgamma, dbeta, dw, None, None, None, None, None, None
         need_affine = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         need_dxn = ctx.needs_input_grad[0] or need_affine
         # GroupNorm's backward statistics without a pass over dxn and x: sum dxn from the data-gradient launch's
@@ -438,7 +501,7 @@ class _SingleConvGCR(torch.autograd.Function):
                 if dx_blocked:
                     dx._kmh_blocked = dx._version
                     BLOCKED_STATS["handoffs"] += 1
-        return dx, dgamma, dbeta, dw, None, None, None, None, None
+        return dx, dgamma, dbeta, dw, None, None, None, None, None, None
 
 
 def _up2_forward(skip, low, scale, shift, ascale, weight, N, D, H, W, Cs, Cl, Cout, ystats):
@@ -596,13 +659,26 @@ def upcat_conv_gcr(skip, low, gamma, beta, weight, num_groups: int, dy_premasked
 
 
 def single_conv_gcr(x, gamma, beta, weight, num_groups: int, x_from_relu: bool = True,
-                    dy_premasked: bool = False, dy_blocked: bool = False, dx_blocked: bool = False) -> Tensor:
+                    dy_premasked: bool = False, dy_blocked: bool = False, dx_blocked: bool = False,
+                    pool: bool = False) -> Tensor:
     """dy_premasked: promise that the gradient arriving for the output is already zero wherever the output is
-    <= 0 (true when all consumers are SingleConvs with x_from_relu=True)."""
+    <= 0 (true when all consumers are SingleConvs with x_from_relu=True).
+    pool: return maxpool2 of the output (see conv_pool_ok); the statistics tagged on it are the pooled tensor's."""
     y, ystats = _SingleConvGCR.apply(x, gamma, beta, weight, num_groups, x_from_relu, dy_premasked, dy_blocked,
-                                     dx_blocked)
+                                     dx_blocked, pool)
     _tag_stats(y, ystats)       # the next GroupNorm's statistics came with the epilogue
     return y
+
+
+POOL_STATS = {"fused": 0}           # convolutions that pooled in their epilogue (tests)
+
+
+def conv_pool_ok(N, D, H, W, Cin, Cout) -> bool:
+    """May relu(conv3(group_norm(x))) be followed by MaxPool3d(2) inside the convolution's epilogue (the output feeds
+    ONLY that pooling and its gradient arrives masked)?  f16x3 mode, 16 < Cout <= 32, the LDS-DMA kernel selected."""
+    if CONV_MODE != "f16x3" or not conv_emits_stats() or os.environ.get("KEYMORPH_NO_CONV_POOL"):
+        return False
+    return bool(_lib.load().kmh_conv3d_fwd_bf_pool_ok(N, D, H, W, Cin, Cout, 2))
 
 
 _NO_ADD = object()
@@ -820,36 +896,74 @@ class _Layout(torch.autograd.Function):
 
 class _ConvBlock(torch.autograd.Function):
     """ConvNet block (keymorph/layers.py:137-187): Conv3d(k3,p1,bias) -> [InstanceNorm3d(affine=False) |
-    GroupNorm(8) | none] -> ReLU.  x, y NDHWC.  (MaxPool is a separate op, like in the reference.)"""
+    GroupNorm(8) | BatchNorm3d | none] -> ReLU.  x, y NDHWC.  (MaxPool is a separate op, like in the reference.)
+
+    bn = 1: BatchNorm3d in training mode.  Its statistics run over (N, D, H, W) per channel, and an NDHWC batch IS one
+    sample of N*D planes in memory, so it is the instance norm of that one "sample" with an affine (gamma, beta): the
+    same kernels with N' = 1, V' = N*V.  The batch statistics are returned for the running averages.
+    bn = 2: BatchNorm3d in evaluation mode: a fixed per-channel affine map from (running_mean, running_var)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, groups):
+    def forward(ctx, x, weight, bias, gamma, beta, groups, bn=0, rmean=None, rvar=None, eps=EPS):
         lib = _lib.load()
         x, weight, bias = _prep(x), _prep(weight), _prep(bias)
         N, D, H, W, Cin = x.shape
         Cout = weight.shape[0]
         V = D * H * W
-        z = conv3_raw(x, None, None, pack_weight(weight, False), bias, N, D, H, W, Cin, Cout, False, groups == 0)
-        if groups == 0:  # norm_type == "none": conv -> ReLU
+        z = conv3_raw(x, None, None, pack_weight(weight, False), bias, N, D, H, W, Cin, Cout, False, groups == 0 and bn == 0)
+        ctx.bn = bn
+        if groups == 0 and bn == 0:  # norm_type == "none": conv -> ReLU
             ctx.save_for_backward(x, weight, z)
             ctx.cfg = (0,)
             return z
-        stats = channel_stats(z, None, N, V, Cout)
-        scale, shift, mr = norm_coeffs(stats, gamma, beta, N, Cout, groups, V)
+        if bn == 2:
+            rstd = torch.rsqrt(rvar.double() + eps)
+            sc1 = (gamma.double() * rstd).float()
+            sh1 = (beta.double() - rmean.double() * gamma.double() * rstd).float()
+            scale, shift = sc1[None].expand(N, Cout).contiguous(), sh1[None].expand(N, Cout).contiguous()
+            y = torch.empty_like(z)
+            check(lib.kmh_norm_apply(_p(z), _p(scale), _p(shift), N, V, Cout, 1, _p(y), _stream()), "kmh_norm_apply")
+            ctx.save_for_backward(x, weight, z, y, scale, gamma, rmean.float(), rstd.float())
+            ctx.cfg = (0,)
+            return y
+        Nn, Vn = (1, N * V) if bn == 1 else (N, V)
+        if bn == 1:
+            groups = Cout
+        stats = channel_stats(z, None, Nn, Vn, Cout)
+        # (kmh_gn_fwd_coeffs takes its epsilon from the module constant: every norm layer of the reference uses 1e-5)
+        scale, shift, mr = norm_coeffs(stats, gamma, beta, Nn, Cout, groups, Vn)
         y = torch.empty_like(z)
-        check(lib.kmh_norm_apply(_p(z), _p(scale), _p(shift), N, V, Cout, 1, _p(y), _stream()), "kmh_norm_apply")
+        check(lib.kmh_norm_apply(_p(z), _p(scale), _p(shift), Nn, Vn, Cout, 1, _p(y), _stream()), "kmh_norm_apply")
         saved = [x, weight, z, y, mr] + ([gamma] if gamma is not None else [])
         ctx.save_for_backward(*saved)
         ctx.cfg = (groups,)
+        if bn == 1:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats=None):
         lib = _lib.load()
         (groups,) = ctx.cfg
         dy = _prep(dy)
         dgamma = dbeta = None
-        if groups == 0:
+        if ctx.bn == 2:
+            x, weight, z, y, scale, gamma, rmean, rstd = ctx.saved_tensors
+            N, D, H, W, Cin = x.shape
+            Cout = weight.shape[0]
+            V = D * H * W
+            dym = torch.empty_like(dy)
+            check(lib.kmh_relu_mask(_p(dy), _p(y), dy.numel(), _p(dym), _stream()), "kmh_relu_mask")
+            ab = channel_stats(dym, z, N, V, Cout).sum(0)                 # (Cout, 2): sum dym, sum dym * z
+            dbeta = ab[:, 0].float()
+            dgamma = ((ab[:, 1] - rmean.double() * ab[:, 0]) * rstd.double()).float()
+            c123 = torch.zeros((N, Cout, 3), dtype=torch.float32, device=x.device)
+            c123[:, :, 0] = scale
+            check(lib.kmh_gn_bwd_apply(_p(dym), _p(z), _p(c123), N, V, Cout, 0, 0, _p(dym), None, 0, _stream()),
+                  "kmh_gn_bwd_apply")
+            dz, dzmask = dym, None
+        elif groups == 0:
             x, weight, y = ctx.saved_tensors
             N, D, H, W, Cin = x.shape
             Cout = weight.shape[0]
@@ -862,15 +976,16 @@ class _ConvBlock(torch.autograd.Function):
             N, D, H, W, Cin = x.shape
             Cout = weight.shape[0]
             V = D * H * W
+            Nn, Vn = (1, N * V) if ctx.bn == 1 else (N, V)
             dym = torch.empty_like(dy)
             check(lib.kmh_relu_mask(_p(dy), _p(y), dy.numel(), _p(dym), _stream()), "kmh_relu_mask")
-            ab = channel_stats(dym, z, N, V, Cout)
-            c123 = _f32((N, Cout, 3), x.device)
+            ab = channel_stats(dym, z, Nn, Vn, Cout)
+            c123 = _f32((Nn, Cout, 3), x.device)
             if gamma is not None:
                 dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)
-            check(lib.kmh_gn_bwd_coeffs(_p(ab), _p(gamma), _p(mr), N, Cout, groups, float(V), _p(c123), _p(dgamma),
+            check(lib.kmh_gn_bwd_coeffs(_p(ab), _p(gamma), _p(mr), Nn, Cout, groups, float(Vn), _p(c123), _p(dgamma),
                                         _p(dbeta), None, _stream()), "kmh_gn_bwd_coeffs")
-            check(lib.kmh_gn_bwd_apply(_p(dym), _p(z), _p(c123), N, V, Cout, 0, 0, _p(dym), None, 0, _stream()),
+            check(lib.kmh_gn_bwd_apply(_p(dym), _p(z), _p(c123), Nn, Vn, Cout, 0, 0, _p(dym), None, 0, _stream()),
                   "kmh_gn_bwd_apply")
             dz, dzmask = dym, None
         dw = conv3_wgrad(x, None, None, dz, N, D, H, W, Cin, Cout, False, dzmask=dzmask)
@@ -884,12 +999,33 @@ class _ConvBlock(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv3_raw(dz, None, None, pack_weight(weight, True), None, N, D, H, W, Cout, Cin, False, False,
                            mask=dzmask)
-        return dx, dw, db, dgamma, dbeta, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None
 
 
 def conv_block(x, weight, bias, gamma=None, beta=None, groups: int = 0) -> Tensor:
     """groups: 0 = no norm, Cout = instance norm (gamma/beta None), 8 = GroupNorm(8) with affine."""
     return _ConvBlock.apply(x, weight, bias, gamma, beta, groups)
+
+
+def conv_block_batchnorm(x, weight, bias, bn: "torch.nn.modules.batchnorm._BatchNorm", training: bool) -> Tensor:
+    """Conv3d(k3,p1,bias) -> BatchNorm3d -> ReLU with torch's BatchNorm semantics (keymorph/layers.py:166-187 with
+    norm_type='batch'): batch statistics + running-average update in training mode (momentum, unbiased running
+    variance, num_batches_tracked), the running statistics as a fixed affine map in evaluation mode."""
+    assert abs(bn.eps - EPS) < 1e-12, "the norm kernels use eps = 1e-5 (what every norm layer of the reference uses)"
+    use_batch = training or not bn.track_running_stats or bn.running_mean is None
+    if not use_batch:
+        return _ConvBlock.apply(x, weight, bias, bn.weight, bn.bias, 0, 2, bn.running_mean, bn.running_var, bn.eps)
+    y, stats = _ConvBlock.apply(x, weight, bias, bn.weight, bn.bias, 0, 1, None, None, bn.eps)
+    if training and bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            n = float(x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3])
+            mean = stats[0, :, 0] / n
+            var = (stats[0, :, 1] / n - mean * mean).clamp_min(0.0)
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            bn.running_var.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).to(bn.running_var.dtype), alpha=mom)
+    return y
 
 
 class _HeadCoM(torch.autograd.Function):

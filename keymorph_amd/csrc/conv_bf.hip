@@ -435,13 +435,20 @@ constexpr int G_LDS_BYTES = G_SLOTS * 16 + G_IMG_BYTES + G_OFF_BYTES;  // 65 280
 typedef __attribute__((address_space(3))) void* kmh_lds_ptr;
 typedef const __attribute__((address_space(1))) void* kmh_glb_ptr;
 
-template <int NT, bool ZP>
+// POOL (NT = 1, not z-paired: 16 < Cout <= 32): the epilogue applies MaxPool3d(2) (floor mode, ATen's first-max rule)
+// to the brick it just computed -- a 32 x 8 x 4 brick at an even origin holds 16 x 4 x 2 whole windows -- and writes
+// ONLY the pooled tensor (N, D/2, H/2, W/2, Cout), the winners' window indices (1 byte per pooled element, the format of
+// kmh_maxpool3d_fwd) and the pooled tensor's (sum, sum^2) statistics: the full-resolution output of an encoder block that
+// feeds nothing but the next level's pooling is never written (8.6 GB per step at 256^3) nor re-read by a pooling pass.
+template <int NT, bool ZP, bool POOL = false>
 __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16x8* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int D, int H, int W, int Cin,
     int Cout, int CoutP, int relu_in, int relu_out, int tiles_x, int tiles_y, int tiles_z, int tiles_zp,
     const float* __restrict__ ascale, const float* __restrict__ wscale, double* __restrict__ stats_partial,
-    int in_blocked, const float* __restrict__ addend, int total_items, int N, long long* __restrict__ trace) {
+    int in_blocked, const float* __restrict__ addend, int total_items, int N, long long* __restrict__ trace,
+    unsigned* __restrict__ pool_arg = nullptr) {
+  static_assert(!POOL || (NT == 1 && !ZP), "the pooling epilogue is built for the 32-wide tile");
   constexpr int TERMS = 2, MR = ZP ? 2 : 4;
   constexpr int NST = ZP ? NSTEP_Z : NSTEP;
   static_assert(!ZP || NT == 1, "z-paired tiles are for Cout <= 16");
@@ -704,6 +711,96 @@ __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
     float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                           // every wave is done with the fragment images
     const int gz = z0 + wz + pl;
+    if constexpr (POOL) {
+      // lane = (channel quad c4, x-pair group j): the wave's row tile is read back as voxel PAIRS (2 j + 16 kk, + 1), so
+      // the x children of a window meet in one lane, its y children in consecutive rows of this wave, and its z
+      // children in the wave two up (same rows, next plane): odd planes hand their (x, y)-pooled partials over through
+      // LDS.  Scan order of the reference (z, y, x; a later value wins only if strictly greater, or NaN) is kept by
+      // combining lower-index halves first.
+      const int j = lane >> 3;
+      float4 pm[2][2];
+      unsigned pa[2][2];
+      auto pick = [](float a, float b, unsigned ca, unsigned cb, float& m_, unsigned& c_) {
+        const bool tb = (b > a) || (b != b);
+        m_ = tb ? b : a; c_ = tb ? cb : ca;
+      };
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * CH + li] = acc[m][0][r];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int xe = 2 * j + 16 * kk;
+          const float4 a = *reinterpret_cast<const float4*>(tile + xe * CH + col);
+          const float4 b = *reinterpret_cast<const float4*>(tile + (xe + 1) * CH + col);
+          float va[4] = {a.x * desc + bv.x, a.y * desc + bv.y, a.z * desc + bv.z, a.w * desc + bv.w};
+          float vb[4] = {b.x * desc + bv.x, b.y * desc + bv.y, b.z * desc + bv.z, b.w * desc + bv.w};
+          float mx[4];
+          unsigned cx[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (relu_out) { va[q] = fmaxf(va[q], 0.f); vb[q] = fmaxf(vb[q], 0.f); }
+            pick(va[q], vb[q], 0u, 1u, mx[q], cx[q]);                      // x children: codes 0 / 1
+          }
+          if ((m & 1) == 0) {
+            pm[m >> 1][kk] = float4{mx[0], mx[1], mx[2], mx[3]};
+            pa[m >> 1][kk] = cx[0] | (cx[1] << 8) | (cx[2] << 16) | (cx[3] << 24);
+          } else {                                                         // y children: + 2 for the second row
+            float4& P = pm[m >> 1][kk];
+            const unsigned A = pa[m >> 1][kk];
+            float o0, o1, o2, o3;
+            unsigned c0, c1, c2, c3;
+            pick(P.x, mx[0], A & 255u, cx[0] + 2u, o0, c0);
+            pick(P.y, mx[1], (A >> 8) & 255u, cx[1] + 2u, o1, c1);
+            pick(P.z, mx[2], (A >> 16) & 255u, cx[2] + 2u, o2, c2);
+            pick(P.w, mx[3], A >> 24, cx[3] + 2u, o3, c3);
+            P = float4{o0, o1, o2, o3};
+            pa[m >> 1][kk] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+          }
+        }
+      }
+      // z children: waves 2, 3, 6, 7 (odd planes) publish, waves 0, 1, 4, 5 (even planes) combine and store
+      float4* xv = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(sIn) + 8 * (32 * CH * 4));   // behind the 8 tiles
+      unsigned* xa = reinterpret_cast<unsigned*>(xv + 4 * 4 * 64);
+      const bool odd_plane = (wz & 1) != 0;
+      const int slot = ((wv >> 2) * 2 + (wv & 1)) * 4 * 64;              // (plane pair, row half)
+      if (odd_plane) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) { xv[slot + (2 * p + kk) * 64 + lane] = pm[p][kk]; xa[slot + (2 * p + kk) * 64 + lane] = pa[p][kk]; }
+      }
+      __syncthreads();
+      if (!odd_plane) {
+        const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1;
+        const int oz = (z0 + wz) >> 1;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int oy = (y0 + wy + 2 * p) >> 1;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int ox = (x0 >> 1) + j + 8 * kk;
+            const float4 Q = xv[slot + (2 * p + kk) * 64 + lane];
+            const unsigned B = xa[slot + (2 * p + kk) * 64 + lane];
+            const float4 P = pm[p][kk];
+            const unsigned A = pa[p][kk];
+            float o0, o1, o2, o3;
+            unsigned c0, c1, c2, c3;
+            pick(P.x, Q.x, A & 255u, (B & 255u) + 4u, o0, c0);
+            pick(P.y, Q.y, (A >> 8) & 255u, ((B >> 8) & 255u) + 4u, o1, c1);
+            pick(P.z, Q.z, (A >> 16) & 255u, ((B >> 16) & 255u) + 4u, o2, c2);
+            pick(P.w, Q.w, A >> 24, (B >> 24) + 4u, o3, c3);
+            if (oz < Do && oy < Ho && ox < Wo && co_ok) {
+              const long long e = ((((long long)n * Do + oz) * Ho + oy) * Wo + ox) * Cout + co;
+              *reinterpret_cast<float4*>(y + e) = float4{o0, o1, o2, o3};
+              pool_arg[e >> 2] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+              st1[0] += o0; st2[0] += o0 * o0; st1[1] += o1; st2[1] += o1 * o1;
+              st1[2] += o2; st2[2] += o2 * o2; st1[3] += o3; st2[3] += o3 * o3;
+            }
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
 #pragma unroll
@@ -735,6 +832,7 @@ __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
         }
       }
     }
+    }   // !POOL
     if (stats_partial) {
       // per (wave, column) sums -> LDS -> one (sum, sum^2) pair per channel and brick, fixed order (deterministic)
       double d1[4], d2[4];
@@ -1414,12 +1512,12 @@ static int launch_fwd_bf(const float* x, const float* scale, const float* shift,
   return KMH_LAUNCH_CHECK();
 }
 
-template <int NT, bool ZP>
+template <int NT, bool ZP, bool POOL = false>
 static int launch_fwd_g(const float* x, const float* scale, const float* shift, const bf16x8* wp, const float* bias,
                         float* y, int N, int D, int H, int W, int Cin, int Cout, int CoutP, int relu_in, int relu_out,
                         const float* ascale, const float* wscale, double* stats_ws, double* stats_out, hipStream_t s,
-                        int in_blocked, const float* addend) {
-  hipError_t e = hipFuncSetAttribute((const void*)conv3_fwd_g_kernel<NT, ZP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        int in_blocked, const float* addend, unsigned* pool_arg = nullptr) {
+  hipError_t e = hipFuncSetAttribute((const void*)conv3_fwd_g_kernel<NT, ZP, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      G_LDS_BYTES);
   if (e != hipSuccess) return (int)e;
   const int tx = ceil_div(W, TX), ty = ceil_div(H, GTY), tz = ceil_div(D, GTZ);
@@ -1435,10 +1533,10 @@ static int launch_fwd_g(const float* x, const float* scale, const float* shift, 
   static const bool tracing = getenv("KMH_G_TRACE") != nullptr;
   if (tracing && !trace) { if (hipMalloc(&trace, 240 * sizeof(long long)) != hipSuccess) trace = nullptr; }
   if (tracing && trace) (void)hipMemsetAsync(trace, 0, 240 * sizeof(long long), s);
-  conv3_fwd_g_kernel<NT, ZP><<<g, G_TPB, G_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in,
-                                                           relu_out, tx, ty, tz, tzp, ascale, wscale,
-                                                           stats_out ? stats_ws : nullptr, in_blocked, addend, total, N,
-                                                           tracing ? trace : nullptr);
+  conv3_fwd_g_kernel<NT, ZP, POOL><<<g, G_TPB, G_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP,
+                                                                 relu_in, relu_out, tx, ty, tz, tzp, ascale, wscale,
+                                                                 stats_out ? stats_ws : nullptr, in_blocked, addend, total, N,
+                                                                 tracing ? trace : nullptr, pool_arg);
   if (tracing && trace) {
     long long h[240];
     (void)hipStreamSynchronize(s);
@@ -1495,6 +1593,28 @@ KMH_API int kmh_conv3d_fwd_bf_variant(int N, int D, int H, int W, int Cin, int C
                                       int has_addend) {
   if (!fwd_g_ok(has_mask != 0, has_addend != 0, N, D, H, W, Cin, Cout, terms)) return 0;
   return use_zpair(Cout) ? 3 : (Cout > 32 ? 2 : 1);
+}
+
+/* Convolution + ReLU + MaxPool3d(2) in one launch, for an encoder block whose output feeds ONLY the next level's pooling
+ * (keymorph/unet3d/buildingblocks.py:46-78 then :321-380 `self.pooling(x)`): yp (N, D/2, H/2, W/2, Cout) = the pooled
+ * output, arg (same shape, 1 byte per element) = the winners' window indices exactly as kmh_maxpool3d_fwd records them
+ * (first maximum in z, y, x order), stats_out (N, Cout, 2) = (sum, sum^2) of the POOLED tensor; the full-resolution
+ * output is never written.  Same arguments otherwise as kmh_conv3d_fwd_bf (no mask, bias, addend).
+ * kmh_conv3d_fwd_bf_pool_ok says whether a shape is served (split-fp16 mode, whole 8-channel input chunks, 16 < Cout <= 32,
+ * and the LDS-DMA kernel selected by the current dispatch mode). */
+KMH_API int kmh_conv3d_fwd_bf_pool_ok(int N, int D, int H, int W, int Cin, int Cout, int terms) {
+  return (Cout > 16 && Cout <= 32 && D >= 2 && H >= 2 && W >= 2 && fwd_g_ok(false, false, N, D, H, W, Cin, Cout, terms)) ? 1 : 0;
+}
+
+KMH_API int kmh_conv3d_fwd_bf_pool(const float* x, const float* scale, const float* shift, const void* packed, float* yp,
+                                   unsigned char* arg, int N, int D, int H, int W, int Cin, int Cout, int relu_in,
+                                   int terms, const float* ascale, const float* wscale, void* stats_ws, double* stats_out,
+                                   int in_blocked, void* stream) {
+  if (!kmh_conv3d_fwd_bf_pool_ok(N, D, H, W, Cin, Cout, terms) || !ascale || !wscale || !yp || !arg) return -22;
+  if (((uintptr_t)yp & 15) || ((uintptr_t)arg & 3)) return -22;
+  return launch_fwd_g<1, false, true>(x, scale, shift, (const bf16x8*)packed, nullptr, yp, N, D, H, W, Cin, Cout,
+                                      cout_pad(Cout), relu_in, 1, ascale, wscale, (double*)stats_ws, stats_out,
+                                      (hipStream_t)stream, in_blocked, nullptr, (unsigned*)arg);
 }
 
 static inline int fwd_bf_rows(int Cout, int rows_per_wave) {   // smallest brick height in y of the variants that may run

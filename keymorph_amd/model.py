@@ -40,6 +40,11 @@ class KeyMorph(nn.Module):
         self.keypoint_layer = CenterOfMass2d(indexing="ij") if dim == 2 else CenterOfMass3d(indexing="ij")
         self.max_train_keypoints = max_train_keypoints
         self.use_amp = use_amp            # fp32 is the parity configuration; accepted for signature parity
+        if use_amp:
+            import warnings
+            warnings.warn("keymorph_amd: use_amp=True is accepted for signature parity and IGNORED -- the path computes "
+                          "fp32 results (split-fp16 matrix-core products, fp32 accumulation) whatever the flag says; the "
+                          "reference would autocast the keypoint extractor to fp16 (keymorph/model.py:176-191)")
         self.use_checkpoint = use_checkpoint
         self.max_rand_tps_lmbda = max_rand_tps_lmbda
         self.supported_transform_type = ["rigid", "affine", "tps"]

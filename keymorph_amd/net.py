@@ -23,7 +23,9 @@ class ConvBlock(nn.Module):
             self.norm = nn.InstanceNorm3d(out_channels)      # affine=False: no parameters, holder only
         elif norm_type == "group":
             self.norm = nn.GroupNorm(num_groups=8, num_channels=out_channels)
-        else:  # "batch" needs running statistics across the data set; not on the hot path
+        elif norm_type == "batch":
+            self.norm = nn.BatchNorm3d(out_channels)         # parameters + running statistics, same state_dict keys
+        else:
             raise NotImplementedError(norm_type)
         self.conv = nn.Conv3d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)  # parameter holder
         self._cout = out_channels
@@ -33,6 +35,8 @@ class ConvBlock(nn.Module):
             out = B.conv_block(x, self.conv.weight, self.conv.bias, None, None, 0)
         elif self.norm_type == "instance":
             out = B.conv_block(x, self.conv.weight, self.conv.bias, None, None, self._cout)
+        elif self.norm_type == "batch":
+            out = B.conv_block_batchnorm(x, self.conv.weight, self.conv.bias, self.norm, self.training)
         else:
             out = B.conv_block(x, self.conv.weight, self.conv.bias, self.norm.weight, self.norm.bias, 8)
         if self.down_sample:

@@ -37,13 +37,13 @@ class SingleConv(nn.Module):
         # through max-pool / upsample+concat), whose backward already masks its dx by (x > 0)
         self._dy_premasked = False
 
-    def forward(self, x, dy_premasked=None, dy_blocked=False, dx_blocked=False):  # x NDHWC
+    def forward(self, x, dy_premasked=None, dy_blocked=False, dx_blocked=False, pool=False):  # x NDHWC
         """dy_premasked overrides the static promise for this call (the fused keypoint head masks its feature gradient);
-        dy_blocked / dx_blocked: see DoubleConv.forward."""
+        dy_blocked / dx_blocked: see DoubleConv.forward; pool: return maxpool2 of the output (B.conv_pool_ok)."""
         return B.single_conv_gcr(x, self.groupnorm.weight, self.groupnorm.bias, self.conv.weight, self._groups,
                                  x_from_relu=not self._first,
                                  dy_premasked=self._dy_premasked if dy_premasked is None else dy_premasked,
-                                 dy_blocked=dy_blocked, dx_blocked=dx_blocked)
+                                 dy_blocked=dy_blocked, dx_blocked=dx_blocked, pool=pool)
 
 
 class DoubleConv(nn.Module):
@@ -60,7 +60,9 @@ class DoubleConv(nn.Module):
         self.SingleConv2 = SingleConv(*c2, num_groups=num_groups)
         self.SingleConv1._dy_premasked = True     # its only consumer, SingleConv2, masks the gradient it returns by (x > 0)
 
-    def forward(self, x, out_premasked=None, out_dy_blocked=False):
+    def forward(self, x, out_premasked=None, out_dy_blocked=False, out_pool=False):
+        # out_pool: the block's output goes ONLY to a max-pool, which the second convolution then applies in its epilogue
+        # (the block returns the POOLED tensor; out_dy_blocked then refers to the scattered gradient inside that operator)
         # out_dy_blocked: the block's output goes ONLY to a max-pool called with blocked_grad=True
         # the hidden activation has exactly one consumer, so its gradient can travel in the layout the first conv's
         # gradient kernels read fastest (channel-blocked, backbone_ops.grad_blocked_ok) -- an internal hand-off
@@ -68,7 +70,7 @@ class DoubleConv(nn.Module):
         blk = (torch.is_grad_enabled() and self.SingleConv1._dy_premasked
                and B.grad_blocked_ok(n, d, h, w, cin, self.SingleConv1.conv.out_channels))
         return self.SingleConv2(self.SingleConv1(x, dy_blocked=blk), out_premasked, dy_blocked=out_dy_blocked,
-                                dx_blocked=blk)
+                                dx_blocked=blk, pool=out_pool)
 
 
 class Encoder(nn.Module):
@@ -158,9 +160,16 @@ class AbstractUNet(nn.Module):
                 n_, d_, h_, w_ = xin.shape[0], xin.shape[1], xin.shape[2], xin.shape[3]
                 blk_out = (d_ % 2 == 0 and h_ % 2 == 0 and w_ % 2 == 0 and
                            B.grad_blocked_ok(n_, d_, h_, w_, c2.conv.in_channels, c2.conv.out_channels))
-            x = enc.basic_module(xin, opm, out_dy_blocked=blk_out)
+            # ... and, when the shapes allow, never exists at full resolution: the second convolution pools in its epilogue
+            fuse_pool = (nxt_pools and opm is None and c2._dy_premasked
+                         and B.conv_pool_ok(xin.shape[0], xin.shape[1], xin.shape[2], xin.shape[3], c2.conv.in_channels,
+                                            c2.conv.out_channels))
+            x = enc.basic_module(xin, opm, out_dy_blocked=blk_out, out_pool=fuse_pool)
             prev_blk = blk_out
-            pooled = None
+            pooled = x if fuse_pool else None
+            if fuse_pool:
+                feats.insert(0, (None, False))       # (not a skip source: the truncated / pooled-only level)
+                continue
             if i in forked and i + 1 < L and self.encoders[i + 1].apply_pooling:
                 pooled, x = B.pool_fork(x)
                 feats.insert(0, (x, True))

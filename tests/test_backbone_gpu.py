@@ -293,6 +293,49 @@ def test_convblock_group_norm():
         close(ga, r.grad, 2e-4 * float(r.grad.abs().max()), 1e-3)
 
 
+def test_convblock_batch_norm():
+    """ConvBlock(norm_type="batch") (keymorph/layers.py:137-187): training mode = batch statistics over (N, D, H, W)
+    + running-average update, evaluation mode = the running statistics as a fixed affine map; forward, every gradient
+    and the buffers against torch's Conv3d -> BatchNorm3d -> ReLU, two training steps then one evaluation pass."""
+    from keymorph_amd import backbone_ops as B
+    from keymorph_amd.net import ConvBlock
+    g = gen(6)
+    Cin, Cout, dims = 16, 24, (6, 5, 10)
+    torch.manual_seed(4)
+    blk = ConvBlock(Cin, Cout, 1, "batch", down_sample=False, dim=3)
+    with torch.no_grad():
+        blk.norm.weight.copy_(1 + 0.1 * torch.randn(Cout, generator=g))
+        blk.norm.bias.copy_(0.1 * torch.randn(Cout, generator=g))
+    ref_conv = torch.nn.Conv3d(Cin, Cout, 3, padding=1)
+    ref_bn = torch.nn.BatchNorm3d(Cout)
+    ref_conv.load_state_dict(blk.conv.state_dict())
+    ref_bn.load_state_dict(blk.norm.state_dict())
+    assert sorted(blk.state_dict()) == sorted(["conv.weight", "conv.bias", "norm.weight", "norm.bias", "norm.running_mean",
+                                               "norm.running_var", "norm.num_batches_tracked"])
+    blk = blk.to(DEV)
+    for step, train in enumerate((True, True, False)):
+        blk.train(train); ref_conv.train(train); ref_bn.train(train)
+        x = torch.randn(3, Cin, *dims, generator=g) + 0.3
+        cot = torch.randn(3, Cout, *dims, generator=g)
+        for m in (blk, ref_conv, ref_bn):
+            m.zero_grad(set_to_none=True)
+        xr = x.clone().requires_grad_(True)
+        yr = F.relu(ref_bn(ref_conv(xr)))
+        (yr * cot).sum().backward()
+        xh = ndhwc(x).to(DEV).requires_grad_(True)
+        yh = blk(xh)
+        (yh * ndhwc(cot).to(DEV)).sum().backward()
+        close(ncdhw(yh), yr, 2e-5, 1e-4)
+        close(ncdhw(xh.grad), xr.grad, 2e-4 * float(xr.grad.abs().max()), 1e-3)
+        for a, r in ((blk.conv.weight, ref_conv.weight), (blk.conv.bias, ref_conv.bias), (blk.norm.weight, ref_bn.weight),
+                     (blk.norm.bias, ref_bn.bias)):
+            # (the conv bias gradient under training-mode batch norm is analytically zero: compare absolutely)
+            close(a.grad, r.grad, 2e-4 * float(r.grad.abs().max()) + 2e-4, 1e-3)
+        close(blk.norm.running_mean, ref_bn.running_mean, 1e-6, 1e-5)
+        close(blk.norm.running_var, ref_bn.running_var, 1e-6, 1e-5)
+        assert int(blk.norm.num_batches_tracked) == int(ref_bn.num_batches_tracked) == min(step + 1, 2)
+
+
 @pytest.mark.parametrize("cfg", [(2, 16, 16, (6, 7, 9)), (1, 64, 200, (8, 8, 20)), (2, 8, 40, (3, 5, 70)),
                                  (1, 32, 130, (16, 16, 16)), (2, 64, 96, (4, 6, 64)), (1, 24, 40, (2, 3, 128))])
 def test_fused_head_matches_unfused(cfg):

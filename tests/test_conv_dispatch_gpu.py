@@ -45,6 +45,7 @@ def group_norm_fp64(x, G, gamma, beta, eps=1e-5):
 
 
 def rel(a, b):
+    a, b = a.detach(), b.detach()
     return float((a.double() - b).abs().max()) / (float(b.abs().max()) + 1e-300)
 
 
@@ -258,5 +259,160 @@ def test_single_conv_layer_ragged_forced_kernel_g_all_gradients_vs_fp64(cfg, dis
         assert rel(Hh[0].grad, R[0].grad) < 5e-6
         assert rel(Hh[3].grad, R[3].grad) < 3e-6
         assert rel(Hh[1].grad, R[1].grad) < 2e-5 and rel(Hh[2].grad, R[2].grad) < 2e-5
+    finally:
+        B.set_conv_mode(old)
+
+
+@pytest.mark.parametrize("log2_ratio", [10, 20, 30])
+def test_gradient_dynamic_range_across_samples(log2_ratio, dispatch):
+    """The f16x3 convolutions carry ONE power-of-two range scale per gradient tensor.  Two samples of one batch whose
+    cotangents differ by 2^r: the faint sample's data gradient keeps hi + lo fp16 terms whose quantum is 2^-24 of the
+    scaled maximum, i.e. its own relative precision is max(2^-22, 2^(r - 39)) -- fp32-class up to r ~ 17, 2e-6 at
+    r = 20, 2e-3 at r = 30.  This test measures it against fp64 (per sample, relative to that sample's own maximum) and
+    pins the supported range: <= 1e-5 for ratios up to 2^20; beyond that `backbone_ops.range_audit` (below) is the
+    detector and bf16x6 (8 exponent bits, no range scale) the arithmetic to switch to."""
+    from keymorph_amd import backbone_ops as B
+    N, D, H, W, Cin, Cout, G = 2, 12, 20, 40, 16, 32, 8
+    old = B.CONV_MODE
+    try:
+        g = gen(77)
+        x = (torch.randn(N, D, H, W, Cin, generator=g).abs() + 0.1 * torch.randn(N, D, H, W, Cin, generator=g)).to(DEV)
+        gamma, beta = (1 + 0.2 * torch.randn(Cin, generator=g)).to(DEV), (0.2 * torch.randn(Cin, generator=g)).to(DEV)
+        w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / np.sqrt(27 * Cin)).to(DEV)
+        cot = torch.randn(N, D, H, W, Cout, generator=g).to(DEV)
+        cot[1] *= 2.0 ** -log2_ratio
+        errs = {}
+        for mode in ("f16x3", "bf16x6"):
+            B.set_conv_mode(mode)
+            Hh = [t.clone().requires_grad_(True) for t in (x, gamma, beta, w)]
+            yh = B.single_conv_gcr(*Hh, G, x_from_relu=False, dy_premasked=True)
+            # cotangent masked by THIS output's sign pattern, the fp64 reference differentiates the pre-activation against
+            # the same masked cotangent (a ReLU flip at |y| ~ 1e-7 would otherwise move the weight gradient by 1e-3)
+            cotm = cot * (yh.detach() > 0)
+            (yh * cotm).sum().backward()
+            R = [t.double().clone().requires_grad_(True) for t in (x, gamma, beta, w)]
+            (conv3_fp64(group_norm_fp64(R[0], G, R[1], R[2]), R[3]) * cotm.double()).sum().backward()
+            errs[mode] = [rel(Hh[0].grad[n], R[0].grad[n]) for n in range(N)]
+            assert rel(Hh[3].grad, R[3].grad) < 3e-6            # the weight gradient is dominated by the loud sample
+        print(f"\ncotangent ratio 2^{log2_ratio}: data-gradient error per sample (own maximum) f16x3 {errs['f16x3']}, "
+              f"bf16x6 {errs['bf16x6']}")
+        assert errs["f16x3"][0] < 5e-6 and errs["bf16x6"][0] < 5e-6 and errs["bf16x6"][1] < 5e-6
+        if log2_ratio <= 20:
+            assert errs["f16x3"][1] < 1e-5, errs
+        else:
+            assert errs["f16x3"][1] < 2.0 ** (log2_ratio - 36), errs      # degrades as predicted, never garbage
+        # the detector: fraction of non-zero gradient elements whose lo term has left fp16's normal range
+        audit = B.range_audit(cot)
+        assert audit["per_sample_log2_below_max"][1] == pytest.approx(log2_ratio, abs=1.0)
+        assert (audit["worst_relative_precision"] > 2.0 ** -21) == (log2_ratio > 18), audit
+    finally:
+        B.set_conv_mode(old)
+
+
+@pytest.mark.parametrize("cfg", [(2, (12, 16, 64), 16, 32), (2, (45, 60, 100), 16, 32), (1, (30, 61, 121), 24, 24),
+                                 (3, (9, 10, 35), 8, 20)])
+def test_conv_epilogue_pooling_equals_conv_then_maxpool(cfg, dispatch, monkeypatch):
+    """GroupNorm -> conv -> ReLU -> MaxPool3d(2) with the pooling done in the convolution's epilogue (the full-resolution
+    output is never written; keymorph/unet3d/buildingblocks.py:46-78 + the next Encoder's pooling) against the same
+    layer followed by the separate pooling kernel: pooled output BIT-identical, identical winners (so identical
+    gradients: every parameter gradient and the input gradient bit for bit), the pooled tensor's statistics, on even,
+    odd and ragged volumes; and the pooled output against F.max_pool3d of the fp64 layer."""
+    from keymorph_amd import backbone_ops as B
+    N, dims, Cin, Cout = cfg
+    D, H, W = dims
+    old = B.CONV_MODE
+    try:
+        B.set_conv_mode("f16x3")
+        dispatch(2)
+        assert B.conv_pool_ok(N, D, H, W, Cin, Cout)
+        g = gen(500 + Cin)
+        x = (torch.randn(N, D, H, W, Cin, generator=g).abs() + 0.1 * torch.randn(N, D, H, W, Cin, generator=g)).to(DEV)
+        gamma, beta = (1 + 0.2 * torch.randn(Cin, generator=g)).to(DEV), (0.2 * torch.randn(Cin, generator=g)).to(DEV)
+        w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / np.sqrt(27 * Cin)).to(DEV)
+        cot = torch.randn(N, D // 2, H // 2, W // 2, Cout, generator=g).to(DEV)
+        G = 8
+
+        def run(fused):
+            Hh = [t.clone().requires_grad_(True) for t in (x, gamma, beta, w)]
+            before = B.POOL_STATS["fused"]
+            if fused:
+                yp = B.single_conv_gcr(*Hh, G, x_from_relu=False, dy_premasked=True, pool=True)
+            else:
+                yp = B.maxpool2(B.single_conv_gcr(*Hh, G, x_from_relu=False, dy_premasked=True))
+            assert B.POOL_STATS["fused"] == before + int(fused)
+            st = B._peek_stats(yp)
+            (yp * (cot * (yp.detach() > 0))).sum().backward()
+            return yp.detach(), st, [t.grad for t in Hh]
+
+        yf, sf, gf = run(True)
+        yu, su, gu = run(False)
+        assert yf.shape == (N, D // 2, H // 2, W // 2, Cout)
+        assert torch.equal(yf, yu), "pooled output differs from conv followed by maxpool"
+        for a, b in zip(gf, gu):
+            assert torch.equal(a, b), "a gradient differs: the recorded winners are not the pooling kernel's"
+        # statistics of the pooled tensor (what the next GroupNorm needs) came with the epilogue
+        assert sf is not None and su is None
+        V = (D // 2) * (H // 2) * (W // 2)
+        ref = B.channel_stats(yf, None, N, V, Cout)
+        assert rel(sf, ref) < 1e-6
+        # and against fp64
+        R = [t.double() for t in (x, gamma, beta, w)]
+        y64 = torch.relu(conv3_fp64(group_norm_fp64(R[0], G, R[1], R[2]), R[3]))
+        p64 = F.max_pool3d(y64.permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1)
+        assert rel(yf, p64) < 3e-6
+    finally:
+        B.set_conv_mode(old)
+
+
+def test_conv_epilogue_pooling_tie_rule_and_whole_network(dispatch):
+    """ties: a constant input makes every window's 8 children equal (ReLU of one value): the winner must be child 0, as
+    ATen's max_pool3d and kmh_maxpool3d_fwd choose; then the whole TruncatedUNet3D with and without the fused
+    pooling gives the same keypoints and parameter gradients."""
+    from keymorph_amd import backbone_ops as B, _lib
+    from keymorph_amd.unet3d.model import TruncatedUNet3D
+    import os
+    old = B.CONV_MODE
+    try:
+        B.set_conv_mode("f16x3")
+        dispatch(2)
+        N, D, H, W, Cin, Cout = 1, 8, 8, 32, 8, 32
+        x = torch.ones(N, D, H, W, Cin, device=DEV)
+        x[0, 4:, :, :, :] = 2.0                                       # two constant slabs: interior windows are all ties
+        gamma, beta = torch.ones(Cin, device=DEV), torch.full((Cin,), 0.5, device=DEV)
+        w = torch.full((Cout, Cin, 3, 3, 3), 0.01, device=DEV)
+        xg = x.clone().requires_grad_(True)
+        yp = B.single_conv_gcr(xg, gamma, beta, w, 8, x_from_relu=False, dy_premasked=True, pool=True)
+        yu = B.maxpool2(B.single_conv_gcr(x, gamma, beta, w, 8, x_from_relu=False, dy_premasked=True))
+        assert torch.equal(yp, yu)
+        (yp.sum()).backward()
+        xu = x.clone().requires_grad_(True)
+        B.maxpool2(B.single_conv_gcr(xu, gamma, beta, w, 8, x_from_relu=False, dy_premasked=True)).sum().backward()
+        assert torch.equal(xg.grad, xu.grad)
+        # whole network
+        torch.manual_seed(5)
+        net = TruncatedUNet3D(1, 16, 1, final_sigmoid=False, f_maps=32, layer_order="gcr", num_groups=8, num_levels=3,
+                              is_segmentation=False, conv_padding=1).to(DEV).train()
+        img = torch.rand(2, 1, 24, 40, 64, generator=gen(9)).to(DEV)
+        outs = {}
+        for fused in (True, False):
+            if fused:
+                os.environ.pop("KEYMORPH_NO_CONV_POOL", None)
+            else:
+                os.environ["KEYMORPH_NO_CONV_POOL"] = "1"
+            try:
+                net.zero_grad(set_to_none=True)
+                before = B.POOL_STATS["fused"]
+                pts = net.keypoints_ij(img)
+                assert B.POOL_STATS["fused"] == before + int(fused)
+                (pts * torch.linspace(-1, 1, pts.numel(), device=DEV).reshape(pts.shape)).sum().backward()
+                outs[fused] = (pts.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()})
+            finally:
+                os.environ.pop("KEYMORPH_NO_CONV_POOL", None)
+        # (not bit for bit: the next GroupNorm's statistics come from the epilogue's brick sums in one case and from a
+        # separate pass over the pooled tensor in the other -- the same numbers in another summation order)
+        assert float((outs[True][0] - outs[False][0]).abs().max()) < 2e-6
+        va = torch.cat([v.reshape(-1).double() for v in outs[True][1].values()])
+        vb = torch.cat([v.reshape(-1).double() for v in outs[False][1].values()])
+        assert float((va - vb).norm() / vb.norm()) < 1e-4
     finally:
         B.set_conv_mode(old)

@@ -288,3 +288,12 @@ def test_f16x3_arithmetic_claim_emulated():
         e = emu.errors(x, w)
         assert e["f16x3"] < 4e-7 and e["f16x3"] < 1.5 * e["bf16x6"] + 1e-8 and e["f16x3"] < e["fp32"], e
     assert e["f16x3_unscaled"] > 100 * e["f16x3"], e        # the tiny-gradient case: scaling is what makes it work
+
+
+def test_use_amp_is_accepted_but_warns():
+    """keymorph/model.py:176-191 autocasts the extractor under use_amp; this path is fp32-only and says so"""
+    import torch.nn as nn
+    from keymorph_amd.model import KeyMorph
+    with pytest.warns(UserWarning, match="use_amp"):
+        km = KeyMorph(nn.Identity(), 4, 3, use_amp=True)
+    assert km.use_amp is True
