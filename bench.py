@@ -445,14 +445,21 @@ def main():
                 ms = ea.elapsed_time(eb)
                 print(f"# {name:18s} {str(meta['shape']):34s} {ms:8.3f} ms {meta['flops'] / ms / 1e9:7.1f} TF", file=sys.stderr)
     # algorithmic bytes of the dominant kernel's launches: input + output tensor of each, once (fp32)
-    conv_name = "kmh_conv3d_fwd" if a.conv == "f32" else "kmh_conv3d_fwd_bf"
-    conv_alg_bytes = [4.0 * m["shape"][0] * m["shape"][1] * m["shape"][2] * m["shape"][3] * (m["shape"][4] + m["shape"][5])
-                      for name, _, _, m in _lib.profiler.records if name == conv_name and m and "shape" in m]
+    # the dominant kernel family: every launch of conv3_fwd_g_kernel / conv3_fwd_bf_kernel, i.e. kmh_conv3d_fwd_bf and its
+    # pooling-epilogue variant kmh_conv3d_fwd_bf_pool (same kernel, the output written pooled: 1/8 of the output bytes)
+    conv_names = ("kmh_conv3d_fwd",) if a.conv == "f32" else ("kmh_conv3d_fwd_bf", "kmh_conv3d_fwd_bf_pool")
+    conv_alg_bytes = [4.0 * m["shape"][0] * m["shape"][1] * m["shape"][2] * m["shape"][3] *
+                      (m["shape"][4] + m["shape"][5] * (0.125 if name.endswith("_pool") else 1.0))
+                      for name, _, _, m in _lib.profiler.records if name in conv_names and m and "shape" in m]
     _lib.profiler.enabled = False
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
 
     if rank == 0:
-        conv = prof.get("kmh_conv3d_fwd" if a.conv == "f32" else "kmh_conv3d_fwd_bf", {"ms": 0.0, "flops": 0.0, "calls": 1})
+        conv = {"ms": 0.0, "flops": 0.0, "calls": 0}
+        for nm in conv_names:
+            for k in conv:
+                conv[k] += prof.get(nm, {}).get(k, 0)
+        conv["calls"] = max(conv["calls"], 1)
         wg = prof.get("kmh_conv3d_wgrad" if a.conv == "f32" else "kmh_conv3d_wgrad_bf", {"ms": 0.0, "flops": 0.0, "calls": 1})
         conv_tf = conv["flops"] / max(conv["ms"], 1e-9) / 1e9
         total_ms = sum(v["ms"] for v in prof.values())

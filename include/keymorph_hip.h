@@ -206,13 +206,17 @@ int kmh_conv3d_up2_dgrad_pack_weight(const float* w, void* packed, int Cout, int
                                      const float* wscale, void* stream);
 int kmh_conv3d_up2_dgrad(const float* dz, const void* packed, float* ds, int N, int Dl, int Hl, int Wl, int Cl, int Cout,
                          int terms, const float* dscale, const float* wscale, void* stream);
-/* weight gradient of the same operator (csrc/norm.hip): G (N, Dl*Hl*Wl, 27, Cout) = 2x2x2 box sums of dz such that
- * dW[tap][ci][co] = sum_m x_low[m][ci] G[m][tap][co] -- one plain matrix product over the low-resolution voxels */
-int kmh_up2_boxsum(const float* dz, float* G, int N, int Dl, int Hl, int Wl, int Cout, void* stream);
-/* C (N, Cl, J) = A^T B per sample over the V low-resolution voxels: A (N, V, Cl) the normalised low tensor, B (N, V, J)
- * the box sums with J = 27 Cout (split-operand MFMA; ascale / bscale = {S, 1/S} of A and B for terms == 2) */
+/* weight gradient of the same operator: dW[tap][ci][co] = sum_m x_low[m][ci] G[m][tap][co] with G the 2x2x2 box sums of
+ * dz -- one matrix product over the low-resolution voxels (autograd of interpolate + cat + conv3d,
+ * keymorph/unet3d/buildingblocks.py:471-475, :46-78).  All 27 G[., tap] are sub-lattices of one box-filtered tensor:
+ * kmh_up2_box writes Box (N, 2Dl+1, 2Hl+1, 2Wl+1, Cout), Box[u+1] = sum of dz over u + {0,1}^3 inside the volume
+ * (csrc/norm.hip), and G[m][tap] = Box[2m + 1 - k] per axis (k = tap + 1) is read in place by the product. */
+int kmh_up2_box(const float* dz, float* box, int N, int Dl, int Hl, int Wl, int Cout, void* stream);
+/* C (N, Cl, 27 Cout) = A^T G per sample over the Dl Hl Wl low-resolution voxels: A (N, Dl Hl Wl, Cl) the normalised low
+ * tensor (split-operand MFMA; ascale / bscale = {S, 1/S} of A and Box for terms == 2); ws: kmh_up2_wgrad_gemm_ws_bytes
+ * with V = Dl Hl Wl, J = 27 Cout */
 size_t kmh_up2_wgrad_gemm_ws_bytes(int N, int V, int Cl, int J);
-int kmh_up2_wgrad_gemm(const float* A, const float* B, float* C, int N, int V, int Cl, int J, int terms,
+int kmh_up2_wgrad_gemm(const float* A, const float* Box, float* C, int N, int Dl, int Hl, int Wl, int Cl, int Cout, int terms,
                        const float* ascale, const float* bscale, void* ws, void* stream);
 int kmh_conv3d_up2_fwd(const float* xl, const float* scale, const float* shift, int Ctot, int cofs, const void* packed,
                        float* y, int N, int Dl, int Hl, int Wl, int Cl, int Cout, int terms, const float* ascale,

@@ -578,15 +578,17 @@ class _UpCatConvGCR(torch.autograd.Function):
             dy = dzm
         dscale = grad_scale(dy) if _needs_range_scales() else None
         # weight gradient (+ the per-sample fold for GroupNorm).  Skip channels: the 27-tap kernel on `skip`.  Upsampled
-        # channels: dW[tap] = sum_m x_low[m] G[m][tap] with G the 2x2x2 box sums of dz (kmh_up2_boxsum) -- one plain
+        # channels: dW[tap] = sum_m x_low[m] G[m][tap] with G the 2x2x2 box sums of dz (kmh_up2_box) -- one plain
         # matrix product over the low-resolution voxels per sample (1/8 of the multiply-adds; library fp32 GEMM)
         bhat_s = torch.zeros((N, Cs), dtype=torch.float64, device=dy.device)
         dw_s = conv3_wgrad(skip, scale[:, :Cs].contiguous(), shift[:, :Cs].contiguous(), dy, N, D, H, W, Cs, Cout, False,
                            xscale=ctx.ascale, dscale=dscale, fold=(weight[:, :Cs].contiguous(), bhat_s))
         if Cout % 4 == 0 and not os.environ.get("KEYMORPH_NO_UPCONV_WGRAD"):
             Vl = V // 8
-            boxes = _f32((N, Vl, 27 * Cout), dy.device)
-            check(lib.kmh_up2_boxsum(_p(dy), _p(boxes), N, D // 2, H // 2, W // 2, Cout, _stream()), "kmh_up2_boxsum")
+            # one box-filtered copy of dz (2x2x2 sums at every offset, the size of dz): the 27 taps' box sums are its
+            # sub-lattices and are read in place by the product (round 2 wrote them out, 27/8 of dz, and read them back)
+            boxes = _f32((N, D + 1, H + 1, W + 1, Cout), dy.device)
+            check(lib.kmh_up2_box(_p(dy), _p(boxes), N, D // 2, H // 2, W // 2, Cout, _stream()), "kmh_up2_box")
             xl = torch.empty_like(low)
             sc_l, sh_l = scale[:, Cs:].contiguous(), shift[:, Cs:].contiguous()   # named: they must outlive the launch
             check(lib.kmh_norm_apply(_p(low), _p(sc_l), _p(sh_l), N, Vl, Cl, 0, _p(xl), _stream()), "kmh_norm_apply")
@@ -596,7 +598,7 @@ class _UpCatConvGCR(torch.autograd.Function):
             bsc = (dscale * torch.tensor([0.125, 8.0], device=dy.device)) if terms == 2 else None   # sums of 8
             if _lib.profiler.enabled:
                 _lib.profiler.meta = {"flops": 2.0 * 27 * Cl * Cout * N * Vl, "shape": (N, Vl, Cl, 27 * Cout)}
-            check(lib.kmh_up2_wgrad_gemm(_p(xl), _p(boxes), _p(dwn), N, Vl, Cl, 27 * Cout, terms,
+            check(lib.kmh_up2_wgrad_gemm(_p(xl), _p(boxes), _p(dwn), N, D // 2, H // 2, W // 2, Cl, Cout, terms,
                                          _p(ctx.ascale if terms == 2 else None), _p(bsc), _p(gws), _stream()),
                   "kmh_up2_wgrad_gemm")
             del boxes, xl

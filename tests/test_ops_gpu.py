@@ -30,7 +30,11 @@ def gen(seed):
 
 # ---------------------------------------------------------------- sampler
 @pytest.mark.parametrize("shape", [((1, 3, 6, 7, 8), (5, 6, 7)), ((2, 1, 16, 12, 20), (16, 12, 20)),
-                                   ((1, 2, 9, 9, 9), (3, 5, 7))])
+                                   ((1, 2, 9, 9, 9), (3, 5, 7)),
+                                   # >= 4 channels: the channel-batched kernels (4 channels' gathers in flight), with a
+                                   # partial last batch (14 = the one-hot segmentation of the Dice branch; 6; 4)
+                                   ((2, 14, 11, 12, 21), (11, 12, 21)), ((1, 6, 7, 9, 33), (8, 10, 40)),
+                                   ((1, 4, 5, 6, 7), (5, 6, 7))])
 def test_grid_sample_fwd_bwd(shape):
     xs, gs = shape
     g = gen(3)
