@@ -209,8 +209,9 @@ int kmh_conv3d_up2_dgrad(const float* dz, const void* packed, float* ds, int N, 
 /* weight gradient of the same operator: dW[tap][ci][co] = sum_m x_low[m][ci] G[m][tap][co] with G the 2x2x2 box sums of
  * dz -- one matrix product over the low-resolution voxels (autograd of interpolate + cat + conv3d,
  * keymorph/unet3d/buildingblocks.py:471-475, :46-78).  All 27 G[., tap] are sub-lattices of one box-filtered tensor:
- * kmh_up2_box writes Box (N, 2Dl+1, 2Hl+1, 2Wl+1, Cout), Box[u+1] = sum of dz over u + {0,1}^3 inside the volume
- * (csrc/norm.hip), and G[m][tap] = Box[2m + 1 - k] per axis (k = tap + 1) is read in place by the product. */
+ * kmh_up2_box writes Box (N, 2,2,2, Dl+1, Hl+1, Wl+1, Cout), Box[q][m'] = sum of dz over u + {0,1}^3 inside the volume
+ * with u + 1 = 2 m' + q per axis (8 parity classes, so that one tap's rows are contiguous; csrc/norm.hip), and
+ * G[m][tap] = Box at u = 2m + 1 - k per axis (k = tap + 1) is read in place by the product. */
 int kmh_up2_box(const float* dz, float* box, int N, int Dl, int Hl, int Wl, int Cout, void* stream);
 /* C (N, Cl, 27 Cout) = A^T G per sample over the Dl Hl Wl low-resolution voxels: A (N, Dl Hl Wl, Cl) the normalised low
  * tensor (split-operand MFMA; ascale / bscale = {S, 1/S} of A and Box for terms == 2); ws: kmh_up2_wgrad_gemm_ws_bytes

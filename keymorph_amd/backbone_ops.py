@@ -587,7 +587,7 @@ class _UpCatConvGCR(torch.autograd.Function):
             Vl = V // 8
             # one box-filtered copy of dz (2x2x2 sums at every offset, the size of dz): the 27 taps' box sums are its
             # sub-lattices and are read in place by the product (round 2 wrote them out, 27/8 of dz, and read them back)
-            boxes = _f32((N, D + 1, H + 1, W + 1, Cout), dy.device)
+            boxes = _f32((N, 8, D // 2 + 1, H // 2 + 1, W // 2 + 1, Cout), dy.device)
             check(lib.kmh_up2_box(_p(dy), _p(boxes), N, D // 2, H // 2, W // 2, Cout, _stream()), "kmh_up2_box")
             xl = torch.empty_like(low)
             sc_l, sh_l = scale[:, Cs:].contiguous(), shift[:, Cs:].contiguous()   # named: they must outlive the launch

@@ -1243,9 +1243,9 @@ __global__ __launch_bounds__(DUP_TPB, 3) void conv3_up2_dgrad_kernel(
 constexpr int GK = 64;                        // voxels per staging step
 constexpr int GPITCH = GK * 2 + 16;           // bytes per LDS row (64 x 2 B + pad: 9 x 16 B, conflict-free b128 reads)
 // Round 3: B is not a stored (V x J) matrix any more.  Column j = (tap, co); its rows are a sub-lattice of the box-filtered
-// gradient (norm.hip: up2_box_kernel), row m of tap (kz, ky, kx) = Box[2m + 1 - k per axis] (+ 1 for the apron), so a
-// thread's column quads fix loop-invariant tap offsets and the row base follows the low voxel (mz, my, mx), which is
-// advanced incrementally (64 voxels per step: no divisions in the loop).
+// gradient (norm.hip: up2_box_kernel, stored by parity class so that a tap's rows are contiguous), row m of tap
+// (kz, ky, kx) = class (k == 1) at m + (k == 0) per axis, so a thread's column quads fix loop-invariant tap offsets and the
+// row base follows the low voxel (mz, my, mx), which is advanced incrementally (64 voxels per step: no divisions).
 template <int TERMS>
 __global__ __launch_bounds__(256, 2) void up2_wgrad_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                 float* __restrict__ Cp, int V, int Cl, int J, int kslab,
@@ -1265,8 +1265,9 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_gemm_kernel(const float* __r
   const float sa = ascale ? ascale[0] : 1.f, sb = bscale ? bscale[0] : 1.f;
   const float desc = (ascale ? ascale[1] : 1.f) * (bscale ? bscale[1] : 1.f);
   const float* An = A + (long long)n * V * Cl;
-  const int HB = 2 * Hl + 1, WB = 2 * Wl + 1;
-  const float* Bn = B + (long long)n * (2 * Dl + 1) * HB * WB * Cout;
+  const int HS = Hl + 1, WS = Wl + 1;                                   // extents of one parity sub-tensor of Box
+  const long long sub = (long long)(Dl + 1) * HS * WS * Cout;
+  const float* Bn = B + (long long)n * 8 * sub;
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1293,9 +1294,11 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_gemm_kernel(const float* __r
     const int e = tid + i * 256, cq = (e & 3) + 4 * (e >> 7), cb = n0 + 4 * cq;
     const int tap = cb / Cout, co = cb - tap * Cout;
     const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-    tapoff[i] = cb < J ? ((long long)((1 - kz) * HB + (1 - ky)) * WB + (1 - kx)) * Cout + co : -1;   // (always >= 0 + base)
+    // tap k reads parity class q = (k == 1) at m' = m + (k == 0), per axis
+    const int cls = ((kz == 1) << 2) | ((ky == 1) << 1) | (kx == 1);
+    tapoff[i] = cb < J ? cls * sub + ((long long)((kz == 0) * HS + (ky == 0)) * WS + (kx == 0)) * Cout + co : 0;
   }
-  auto box_row = [&](int z, int y, int x) { return (((long long)(2 * z + 1) * HB + (2 * y + 1)) * WB + (2 * x + 1)) * Cout; };
+  auto box_row = [&](int z, int y, int x) { return (((long long)z * HS + y) * WS + x) * Cout; };
   auto fetch = [&](int k0) {
     const int k = k0 + 2 * kp_t;
     // the pair's second voxel: the next one in x, or the first of the next row / plane (odd Wl)
@@ -1409,13 +1412,13 @@ KMH_API size_t kmh_up2_wgrad_gemm_ws_bytes(int N, int V, int Cl, int J) {
 }
 
 /* C (N, Cl, 27 Cout) = A^T G per sample: A (N, Dl Hl Wl, Cl) the normalised low tensor, G[m][tap] = Box[2m + 1 - k] the
- * box sums read in place from Box (N, 2Dl+1, 2Hl+1, 2Wl+1, Cout) (kmh_up2_box); Cl % 4 == 0, Cout % 4 == 0; ascale /
+ * box sums read in place from Box (N, 2,2,2, Dl+1, Hl+1, Wl+1, Cout) (kmh_up2_box); Cl % 4 == 0, Cout % 4 == 0; ascale /
  * bscale = {S, 1/S} range scales of A and Box (terms == 2). */
 KMH_API int kmh_up2_wgrad_gemm(const float* A, const float* Box, float* C, int N, int Dl, int Hl, int Wl, int Cl, int Cout,
                                int terms, const float* ascale, const float* bscale, void* ws, void* stream) {
   const long long Vll = (long long)Dl * Hl * Wl;
   if ((Cl & 3) || (Cout & 3) || (terms != 2 && terms != 3) || (terms == 2 && (!ascale || !bscale)) || Vll >= (1ll << 31) ||
-      (long long)(2 * Dl + 1) * (2 * Hl + 1) * (2 * Wl + 1) * Cout >= (1ll << 40))
+      8ll * (Dl + 1) * (Hl + 1) * (Wl + 1) * Cout >= (1ll << 40))
     return -22;
   const int V = (int)Vll, J = 27 * Cout;
   int ks;

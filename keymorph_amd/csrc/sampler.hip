@@ -287,7 +287,7 @@ __device__ __forceinline__ void unstage_rows(float* __restrict__ dst, int cnt, c
 // FUSE_GRAD (with FUSE_MSE): the loss is mean((out - fixed)^2), whose cotangent 2 (out - fixed) / count is known right
 // here, so the same pass also produces d(loss)/d(grid) -- the rows of the staged grid are overwritten with it and written
 // out like the grid came in.  One launch and 36 B per voxel instead of three (warp, MSE backward, grid backward) and 68.
-template <int MODE, bool FUSE_MSE, bool FUSE_GRAD = false, int CB = 1>
+template <int MODE, bool FUSE_MSE, bool FUSE_GRAD = false>
 __global__ __launch_bounds__(TPB) void sample_fwd_lc_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ out,
     const float* __restrict__ fixed, double* __restrict__ partial, int C, int D, int H, int W, long long ovox,
@@ -322,60 +322,47 @@ __global__ __launch_bounds__(TPB) void sample_fwd_lc_kernel(
     float ggx[ILP], ggy[ILP], ggz[ILP];
 #pragma unroll
     for (int u = 0; u < ILP; ++u) ggx[u] = ggy[u] = ggz[u] = 0.f;
-    // CB channels per trip: their gathers (CB x ILP x 4 pair loads) are in flight together -- a one-hot segmentation
-    // (C = 14, the Dice branch) is otherwise 14 serial memory latencies per voxel pass
-    for (int c0 = 0; c0 < C; c0 += CB) {
-      float o[CB][ILP], fv[CB][ILP];
-      float v[CB][ILP][8];
+    for (int c = 0; c < C; ++c) {
+      const float* p = x + ((long long)n * C + c) * plane;
+      const long long ob = ((long long)n * C + c) * ovox + vb;
+      float o[ILP], fv[ILP];
+      if (FUSE_MSE) {
 #pragma unroll
-      for (int cc = 0; cc < CB; ++cc) {
-        const int c = c0 + cc < C ? c0 + cc : C - 1;          // a clamped channel is loaded again and not stored
-        const float* p = x + ((long long)n * C + c) * plane;
-        const long long ob = ((long long)n * C + c) * ovox + vb;
-        if (FUSE_MSE) {
+        for (int u = 0; u < ILP; ++u) fv[u] = (tid + (j0 + u) * TPB < cnt) ? fixed[ob + tid + (j0 + u) * TPB] : 0.f;
+      }
+      if (MODE == 0) {
+        float v[ILP][8];
 #pragma unroll
-          for (int u = 0; u < ILP; ++u) fv[cc][u] = (tid + (j0 + u) * TPB < cnt) ? fixed[ob + tid + (j0 + u) * TPB] : 0.f;
+        for (int u = 0; u < ILP; ++u) gather8_pairs(p, q[u], v[u]);
+#pragma unroll
+        for (int u = 0; u < ILP; ++u) o[u] = blend8(v[u], t[u]);
+        if (FUSE_GRAD) {
+#pragma unroll
+          for (int u = 0; u < ILP; ++u) {
+            const float fx = t[u].fx, fy = t[u].fy, fz = t[u].fz;
+            const float ax = 1.f - fx, ay = 1.f - fy, az = 1.f - fz;
+            const float* w = v[u];
+            // d/dix, d/diy, d/diz of the trilinear blend (ATen grid_sampler_3d_backward), as sample_bwd_grid_lc_kernel
+            const float dx = -w[0] * (ay * az) + w[1] * (ay * az) - w[2] * (fy * az) + w[3] * (fy * az)
+                             - w[4] * (ay * fz) + w[5] * (ay * fz) - w[6] * (fy * fz) + w[7] * (fy * fz);
+            const float dy = -w[0] * (ax * az) - w[1] * (fx * az) + w[2] * (ax * az) + w[3] * (fx * az)
+                             - w[4] * (ax * fz) - w[5] * (fx * fz) + w[6] * (ax * fz) + w[7] * (fx * fz);
+            const float dz = -w[0] * (ax * ay) - w[1] * (fx * ay) - w[2] * (ax * fy) - w[3] * (fx * fy)
+                             + w[4] * (ax * ay) + w[5] * (fx * ay) + w[6] * (ax * fy) + w[7] * (fx * fy);
+            const float go = (tid + (j0 + u) * TPB < cnt) ? (o[u] - fv[u]) * gcoef : 0.f;
+            ggx[u] += dx * go; ggy[u] += dy * go; ggz[u] += dz * go;
+          }
         }
-        if (MODE == 0) {
+      } else {
 #pragma unroll
-          for (int u = 0; u < ILP; ++u) gather8_pairs(p, q[u], v[cc][u]);
-        } else {
-#pragma unroll
-          for (int u = 0; u < ILP; ++u) o[cc][u] = p[near[u]];
-        }
+        for (int u = 0; u < ILP; ++u) o[u] = p[near[u]];
       }
 #pragma unroll
-      for (int cc = 0; cc < CB; ++cc) {
-        if (c0 + cc >= C) break;
-        const long long ob = ((long long)n * C + c0 + cc) * ovox + vb;
-        if (MODE == 0) {
-#pragma unroll
-          for (int u = 0; u < ILP; ++u) o[cc][u] = blend8(v[cc][u], t[u]);
-          if (FUSE_GRAD) {
-#pragma unroll
-            for (int u = 0; u < ILP; ++u) {
-              const float fx = t[u].fx, fy = t[u].fy, fz = t[u].fz;
-              const float ax = 1.f - fx, ay = 1.f - fy, az = 1.f - fz;
-              const float* w = v[cc][u];
-              // d/dix, d/diy, d/diz of the trilinear blend (ATen grid_sampler_3d_backward), as sample_bwd_grid_lc_kernel
-              const float dx = -w[0] * (ay * az) + w[1] * (ay * az) - w[2] * (fy * az) + w[3] * (fy * az)
-                               - w[4] * (ay * fz) + w[5] * (ay * fz) - w[6] * (fy * fz) + w[7] * (fy * fz);
-              const float dy = -w[0] * (ax * az) - w[1] * (fx * az) + w[2] * (ax * az) + w[3] * (fx * az)
-                               - w[4] * (ax * fz) - w[5] * (fx * fz) + w[6] * (ax * fz) + w[7] * (fx * fz);
-              const float dz = -w[0] * (ax * ay) - w[1] * (fx * ay) - w[2] * (ax * fy) - w[3] * (fx * fy)
-                               + w[4] * (ax * ay) + w[5] * (fx * ay) + w[6] * (ax * fy) + w[7] * (fx * fy);
-              const float go = (tid + (j0 + u) * TPB < cnt) ? (o[cc][u] - fv[cc][u]) * gcoef : 0.f;
-              ggx[u] += dx * go; ggy[u] += dy * go; ggz[u] += dz * go;
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < ILP; ++u) {
-          const int l = tid + (j0 + u) * TPB;
-          if (l < cnt) {
-            if (FUSE_MSE) { const float d = o[cc][u] - fv[cc][u]; acc += d * d; }
-            if (out) out[ob + l] = o[cc][u];
-          }
+      for (int u = 0; u < ILP; ++u) {
+        const int l = tid + (j0 + u) * TPB;
+        if (l < cnt) {
+          if (FUSE_MSE) { const float d = o[u] - fv[u]; acc += d * d; }
+          if (out) out[ob + l] = o[u];
         }
       }
     }
@@ -398,7 +385,6 @@ __global__ __launch_bounds__(TPB) void sample_fwd_lc_kernel(
   }
 }
 
-template <int CB>
 __global__ __launch_bounds__(TPB) void sample_bwd_grid_lc_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ gout,
     float* __restrict__ dgrid, int C, int D, int H, int W, long long ovox) {
@@ -424,38 +410,29 @@ __global__ __launch_bounds__(TPB) void sample_bwd_grid_lc_kernel(
       if (l >= cnt) { q[u].r00 = q[u].r01 = q[u].r10 = q[u].r11 = 0; q[u].sel = false; }
       gx[u] = gy[u] = gz[u] = 0.f;
     }
-    for (int c0 = 0; c0 < C; c0 += CB) {     // CB channels' gathers in flight together (see sample_fwd_lc_kernel)
-      float v[CB][ILP][8], go[CB][ILP];
+    for (int c = 0; c < C; ++c) {
+      const float* p = x + ((long long)n * C + c) * plane;
+      const long long ob = ((long long)n * C + c) * ovox + vb;
+      float v[ILP][8], go[ILP];
 #pragma unroll
-      for (int cc = 0; cc < CB; ++cc) {
-        const bool live = c0 + cc < C;
-        const int c = live ? c0 + cc : C - 1;
-        const float* p = x + ((long long)n * C + c) * plane;
-        const long long ob = ((long long)n * C + c) * ovox + vb;
-#pragma unroll
-        for (int u = 0; u < ILP; ++u) {
-          const int l = tid + (j0 + u) * TPB;
-          go[cc][u] = (live && l < cnt) ? gout[ob + l] : 0.f;
-          gather8_pairs(p, q[u], v[cc][u]);
-        }
+      for (int u = 0; u < ILP; ++u) {
+        const int l = tid + (j0 + u) * TPB;
+        go[u] = l < cnt ? gout[ob + l] : 0.f;
+        gather8_pairs(p, q[u], v[u]);
       }
 #pragma unroll
-      for (int cc = 0; cc < CB; ++cc) {
-        if (c0 + cc >= C) break;
-#pragma unroll
-        for (int u = 0; u < ILP; ++u) {
-          const float fx = t[u].fx, fy = t[u].fy, fz = t[u].fz;
-          const float ax = 1.f - fx, ay = 1.f - fy, az = 1.f - fz;
-          const float* w = v[cc][u];
-          // d/dix, d/diy, d/diz of the trilinear blend (ATen grid_sampler_3d_backward)
-          const float dx = -w[0] * (ay * az) + w[1] * (ay * az) - w[2] * (fy * az) + w[3] * (fy * az)
-                           - w[4] * (ay * fz) + w[5] * (ay * fz) - w[6] * (fy * fz) + w[7] * (fy * fz);
-          const float dy = -w[0] * (ax * az) - w[1] * (fx * az) + w[2] * (ax * az) + w[3] * (fx * az)
-                           - w[4] * (ax * fz) - w[5] * (fx * fz) + w[6] * (ax * fz) + w[7] * (fx * fz);
-          const float dz = -w[0] * (ax * ay) - w[1] * (fx * ay) - w[2] * (ax * fy) - w[3] * (fx * fy)
-                           + w[4] * (ax * ay) + w[5] * (fx * ay) + w[6] * (ax * fy) + w[7] * (fx * fy);
-          gx[u] += dx * go[cc][u]; gy[u] += dy * go[cc][u]; gz[u] += dz * go[cc][u];
-        }
+      for (int u = 0; u < ILP; ++u) {
+        const float fx = t[u].fx, fy = t[u].fy, fz = t[u].fz;
+        const float ax = 1.f - fx, ay = 1.f - fy, az = 1.f - fz;
+        const float* w = v[u];
+        // d/dix, d/diy, d/diz of the trilinear blend (ATen grid_sampler_3d_backward)
+        const float dx = -w[0] * (ay * az) + w[1] * (ay * az) - w[2] * (fy * az) + w[3] * (fy * az)
+                         - w[4] * (ay * fz) + w[5] * (ay * fz) - w[6] * (fy * fz) + w[7] * (fy * fz);
+        const float dy = -w[0] * (ax * az) - w[1] * (fx * az) + w[2] * (ax * az) + w[3] * (fx * az)
+                         - w[4] * (ax * fz) - w[5] * (fx * fz) + w[6] * (ax * fz) + w[7] * (fx * fz);
+        const float dz = -w[0] * (ax * ay) - w[1] * (fx * ay) - w[2] * (ax * fy) - w[3] * (fx * fy)
+                         + w[4] * (ax * ay) + w[5] * (fx * ay) + w[6] * (ax * fy) + w[7] * (fx * fy);
+        gx[u] += dx * go[u]; gy[u] += dy * go[u]; gz[u] += dz * go[u];
       }
     }
 #pragma unroll
@@ -683,9 +660,7 @@ KMH_API int kmh_grid_sample3d_fwd(const float* x, const float* grid, float* out,
   dim3 g(ceil_div(ovox, (long long)TPB * VPT), N);
   hipStream_t s = (hipStream_t)stream;
   if (lane_contiguous_ok(D, H, W)) {
-    if (mode == 0 && C >= 4)     // several channels (one-hot segmentations): 4 channels' gathers in flight together
-      sample_fwd_lc_kernel<0, false, false, 4><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox);
-    else if (mode == 0)
+    if (mode == 0)
       sample_fwd_lc_kernel<0, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox);
     else
       sample_fwd_lc_kernel<1, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox);
@@ -760,10 +735,8 @@ KMH_API int kmh_grid_sample3d_bwd_grid(const float* x, const float* grid, const 
                                        void* stream) {
   const long long ovox = (long long)Do * Ho * Wo;
   dim3 g(ceil_div(ovox, (long long)TPB * VPT), N);
-  if (lane_contiguous_ok(D, H, W) && C >= 4)
-    sample_bwd_grid_lc_kernel<4><<<g, TPB, 0, (hipStream_t)stream>>>(x, grid, gout, dgrid, C, D, H, W, ovox);
-  else if (lane_contiguous_ok(D, H, W))
-    sample_bwd_grid_lc_kernel<1><<<g, TPB, 0, (hipStream_t)stream>>>(x, grid, gout, dgrid, C, D, H, W, ovox);
+  if (lane_contiguous_ok(D, H, W))
+    sample_bwd_grid_lc_kernel<<<g, TPB, 0, (hipStream_t)stream>>>(x, grid, gout, dgrid, C, D, H, W, ovox);
   else
     sample_bwd_grid_kernel<<<g, TPB, 0, (hipStream_t)stream>>>(x, grid, gout, dgrid, C, D, H, W, ovox);
   return KMH_LAUNCH_CHECK();

@@ -266,9 +266,20 @@ class KeyMorph(nn.Module):
             res = {"time": time.time() - start_time, "grouppoints_m": group_points, "grouppoints_a": curr_points}
 
             grids = []
-            for i in mine:
-                al = self._make_aligner_plain(align_type, group_points[i:i + 1], mean_points, tps_lmbda)
-                grid = al.get_flow_field(grid_shape, compute_on_subgrids=True)
+            # the final maps (model.py:453-510: mean -> subject): all of this rank's subjects are fitted in ONE launch
+            # (one CU per system), each grid is then evaluated and saved / kept on its own
+            from . import ops
+            if len(mine):
+                sel = torch.as_tensor(list(mine), device=group_points.device)
+                pm_all = group_points.index_select(0, sel)
+                al_all = self._make_aligner_plain(align_type, pm_all, mean_points.expand_as(pm_all).contiguous(),
+                                                  None if tps_lmbda is None else lm_all[:len(mine)].contiguous())
+            for j, i in enumerate(mine):
+                if align_type == "tps":
+                    grid = ops.tps_grid(al_all.inverse_theta[j:j + 1].contiguous(), al_all.points_f[j:j + 1].contiguous(),
+                                        grid_shape[2:])
+                else:
+                    grid = ops.affine_grid(al_all.inverse_transform_matrix[j:j + 1, :3, :].contiguous(), grid_shape[2:])
                 if kwargs.get("save_results_to_disk") and save_dir:
                     path = f"{save_dir}/{align_type_str}_grid_{i:03}.npy"
                     log(f"-> Saving grid {i + 1}/{len(curr_points)} to {path}")

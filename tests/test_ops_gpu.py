@@ -31,8 +31,7 @@ def gen(seed):
 # ---------------------------------------------------------------- sampler
 @pytest.mark.parametrize("shape", [((1, 3, 6, 7, 8), (5, 6, 7)), ((2, 1, 16, 12, 20), (16, 12, 20)),
                                    ((1, 2, 9, 9, 9), (3, 5, 7)),
-                                   # >= 4 channels: the channel-batched kernels (4 channels' gathers in flight), with a
-                                   # partial last batch (14 = the one-hot segmentation of the Dice branch; 6; 4)
+                                   # many channels (14 = the one-hot segmentation of the Dice branch)
                                    ((2, 14, 11, 12, 21), (11, 12, 21)), ((1, 6, 7, 9, 33), (8, 10, 40)),
                                    ((1, 4, 5, 6, 7), (5, 6, 7))])
 def test_grid_sample_fwd_bwd(shape):
@@ -48,7 +47,7 @@ def test_grid_sample_fwd_bwd(shape):
     out = ops().grid_sample3d(x.to(DEV), gh)
     (out * cot.to(DEV)).sum().backward()
     close(out, ref, 1e-6)
-    close(gh.grad, gr.grad, 2e-5, 1e-5)
+    close(gh.grad, gr.grad, 2e-5 * max(1, xs[1] // 2), 3e-5)      # a sum over the channels: rounding grows with C
     close(ops().grid_sample3d(x.to(DEV), grid.to(DEV), "nearest"), O.align_img(grid, x, "nearest"), 0)
 
 
