@@ -206,18 +206,13 @@ int kmh_conv3d_up2_dgrad_pack_weight(const float* w, void* packed, int Cout, int
                                      const float* wscale, void* stream);
 int kmh_conv3d_up2_dgrad(const float* dz, const void* packed, float* ds, int N, int Dl, int Hl, int Wl, int Cl, int Cout,
                          int terms, const float* dscale, const float* wscale, void* stream);
-/* weight gradient of the same operator: dW[tap][ci][co] = sum_m x_low[m][ci] G[m][tap][co] with G the 2x2x2 box sums of
- * dz -- one matrix product over the low-resolution voxels (autograd of interpolate + cat + conv3d,
- * keymorph/unet3d/buildingblocks.py:471-475, :46-78).  All 27 G[., tap] are sub-lattices of one box-filtered tensor:
- * kmh_up2_box writes Box (N, 2,2,2, Dl+1, Hl+1, Wl+1, Cout), Box[q][m'] = sum of dz over u + {0,1}^3 inside the volume
- * with u + 1 = 2 m' + q per axis (8 parity classes, so that one tap's rows are contiguous; csrc/norm.hip), and
- * G[m][tap] = Box at u = 2m + 1 - k per axis (k = tap + 1) is read in place by the product. */
-int kmh_up2_box(const float* dz, float* box, int N, int Dl, int Hl, int Wl, int Cout, void* stream);
-/* C (N, Cl, 27 Cout) = A^T G per sample over the Dl Hl Wl low-resolution voxels: A (N, Dl Hl Wl, Cl) the normalised low
- * tensor (split-operand MFMA; ascale / bscale = {S, 1/S} of A and Box for terms == 2); ws: kmh_up2_wgrad_gemm_ws_bytes
- * with V = Dl Hl Wl, J = 27 Cout */
+/* weight gradient of the same operator (csrc/norm.hip): G (N, Dl*Hl*Wl, 27, Cout) = 2x2x2 box sums of dz such that
+ * dW[tap][ci][co] = sum_m x_low[m][ci] G[m][tap][co] -- one plain matrix product over the low-resolution voxels */
+int kmh_up2_boxsum(const float* dz, float* G, int N, int Dl, int Hl, int Wl, int Cout, void* stream);
+/* C (N, Cl, J) = A^T B per sample over the V low-resolution voxels: A (N, V, Cl) the normalised low tensor, B (N, V, J)
+ * the box sums with J = 27 Cout (split-operand MFMA; ascale / bscale = {S, 1/S} of A and B for terms == 2) */
 size_t kmh_up2_wgrad_gemm_ws_bytes(int N, int V, int Cl, int J);
-int kmh_up2_wgrad_gemm(const float* A, const float* Box, float* C, int N, int Dl, int Hl, int Wl, int Cl, int Cout, int terms,
+int kmh_up2_wgrad_gemm(const float* A, const float* B, float* C, int N, int V, int Cl, int J, int terms,
                        const float* ascale, const float* bscale, void* ws, void* stream);
 int kmh_conv3d_up2_fwd(const float* xl, const float* scale, const float* shift, int Ctot, int cofs, const void* packed,
                        float* y, int N, int Dl, int Hl, int Wl, int Cl, int Cout, int terms, const float* ascale,
@@ -245,8 +240,10 @@ int kmh_conv3d_first_layer_fwd(const float* x, const float* scale, const float* 
  * 1-channel data gradient: rs (N,Cout,2,27) = correlations of dz with the RAW input (R) and with the indicator of the
  * volume (S), by a dedicated exact-fp32 kernel (Cout <= 16); then ... */
 size_t kmh_conv3d_first_layer_wgrad_ws_bytes(int N, int D, int H, int W, int Cout);
-int kmh_conv3d_first_layer_wgrad(const float* x, const float* dz, const float* dzmask, float* rs, int N, int D, int H,
-                                 int W, int Cout, void* ws, void* stream);
+/* c123 (N,Cout,3) | NULL (needs dzmask): the gradient entering the correlations is [dzmask > 0] (c1 dz + c2 dzmask + c3)
+ * -- the NEXT layer's GroupNorm backward (what kmh_gn_bwd_apply would have written) applied while dz is staged */
+int kmh_conv3d_first_layer_wgrad(const float* x, const float* dz, const float* dzmask, const float* c123, float* rs, int N,
+                                 int D, int H, int W, int Cout, void* ws, void* stream);
 /* ... fold the (x, 1) correlations of one sample into dw and GroupNorm's (A, B) sums */
 int kmh_conv3d_first_layer_fold(const float* rs, const float* w, const float* scale_n, const float* shift_n,
                                 int Cout, float* dw, double* ab_n, int accumulate, void* stream);

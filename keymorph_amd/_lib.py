@@ -68,9 +68,9 @@ PROTOS = {
     "kmh_conv3d_up2_dgrad_pack_bytes": (_sz, [_i, _i, _i]),
     "kmh_conv3d_up2_dgrad_pack_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f]),
     "kmh_conv3d_up2_dgrad": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
-    "kmh_up2_box": (_i, [_f, _f, _i, _i, _i, _i, _i, _f]),
+    "kmh_up2_boxsum": (_i, [_f, _f, _i, _i, _i, _i, _i, _f]),
     "kmh_up2_wgrad_gemm_ws_bytes": (_sz, [_i, _i, _i, _i]),
-    "kmh_up2_wgrad_gemm": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "kmh_up2_wgrad_gemm": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "kmh_conv3d_up2_pack_bytes": (_sz, [_i, _i, _i]),
     "kmh_conv3d_up2_pack_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f]),
     "kmh_conv3d_up2_fwd": (_i, [_f, _f, _f, _i, _i, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
@@ -81,7 +81,7 @@ PROTOS = {
     "kmh_conv3d_wgrad_bf": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _f, _f, _f]),
     "kmh_conv3d_wgrad_bf_blocked_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "kmh_conv3d_first_layer_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "kmh_conv3d_first_layer_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f]),
+    "kmh_conv3d_first_layer_wgrad": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f]),
     "kmh_conv3d_first_layer_fold": (_i, [_f, _f, _f, _f, _i, _f, _f, _i, _f]),
     "kmh_conv3d_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "kmh_conv3d_wgrad": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f]),

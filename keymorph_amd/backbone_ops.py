@@ -254,7 +254,7 @@ def conv3_wgrad(x, scale, shift, dz, N, D, H, W, Cin, Cout, relu_in, dzmask=None
     return dw
 
 
-def first_layer_grads(x, scale, shift, mr, gamma, weight, dy, ymask, N, D, H, W, Cout, G, dscale=None):
+def first_layer_grads(x, scale, shift, mr, gamma, weight, dy, ymask, N, D, H, W, Cout, G, dscale=None, lazy_c123=None):
     """Backward of the FIRST U-Net conv (Cin = 1, input image needs no gradient): the correlations of dz with the RAW
     input (R = x * dz) and with the volume's indicator (S = 1 * dz) give dW = scale R + shift S and GroupNorm's
     (sum dxn, sum dxn x) = (sum W S, sum W R) from 27 x Cout numbers per sample -- the 1-channel data gradient (a full
@@ -269,12 +269,15 @@ def first_layer_grads(x, scale, shift, mr, gamma, weight, dy, ymask, N, D, H, W,
         ws = workspace(int(lib.kmh_conv3d_first_layer_wgrad_ws_bytes(N, D, H, W, Cout)), x.device, "wgrad")
         if _lib.profiler.enabled:
             _lib.profiler.meta = {"flops": 2.0 * 27 * 2 * Cout * V * N, "shape": (N, D, H, W, 1, Cout)}
-        check(lib.kmh_conv3d_first_layer_wgrad(_p(x), _p(dy), _p(ymask), _p(rs), N, D, H, W, Cout, _p(ws), _stream()),
-              "kmh_conv3d_first_layer_wgrad")
+        # lazy_c123: dy is the next layer's normalised-input gradient and ymask that layer's input (= this layer's output):
+        # its GroupNorm backward is applied while the kernel stages the gradient (see _SingleConvGCR.backward, dx_lazy)
+        check(lib.kmh_conv3d_first_layer_wgrad(_p(x), _p(dy), _p(ymask), _p(lazy_c123), _p(rs), N, D, H, W, Cout, _p(ws),
+                                               _stream()), "kmh_conv3d_first_layer_wgrad")
         for n in range(N):
             check(lib.kmh_conv3d_first_layer_fold(_p(rs[n]), _p(weight), _p(scale[n]), _p(shift[n]), Cout, _p(dw),
                                                   _p(ab[n]), int(n > 0), _stream()), "kmh_conv3d_first_layer_fold")
     else:
+        assert lazy_c123 is None
         terms = _TERMS[CONV_MODE]
         rs = _f32((Cout, 2, 3, 3, 3), x.device)
         ws = workspace(int(lib.kmh_conv3d_wgrad_bf_ws_bytes(1, D, H, W, 2, Cout, terms)), x.device, "wgrad")
@@ -352,12 +355,16 @@ class _SingleConvGCR(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, weight, num_groups, x_from_relu, dy_premasked, dy_blocked=False, dx_blocked=False,
-                pool=False):
+                pool=False, dy_lazy=False, dx_lazy=False):
         """dy_blocked: the ONLY consumer of y is a SingleConv called with dx_blocked=True (it returns y's gradient
         channel-blocked, see grad_blocked_ok); dx_blocked: x is the output of a SingleConv called with dy_blocked=True.
         pool: return maxpool2(y) instead of y, computed in the convolution's epilogue (conv_pool_ok): y itself is never
         written; the backward scatters the pooled gradient through the recorded winners (channel-blocked when dy_blocked)
-        and continues as usual."""
+        and continues as usual.
+        dx_lazy / dy_lazy (a hand-off between the second and the FIRST convolution of the first encoder block, whose input
+        image needs no gradient): the second returns its normalised-input gradient dxn UNTOUCHED, tagged with GroupNorm's
+        backward coefficients and its input; the first layer's correlation kernel applies them while it stages the
+        gradient (lazy_first_layer_ok) -- the pass that would write the 256^3 x 16-channel gradient is gone."""
         upsrc = _up_sources(x)
         x, gamma, beta, weight = _prep(x), _prep(gamma), _prep(beta), _prep(weight)
         N, D, H, W, Cin = x.shape
@@ -414,6 +421,7 @@ class _SingleConvGCR(torch.autograd.Function):
         ctx.ascale = ascale               # range scale of the normalised input (f16x3), reused by the weight gradient
         ctx.cfg = (num_groups, bool(x_from_relu), bool(dy_premasked))
         ctx.blocked = (bool(dy_blocked), bool(dx_blocked))
+        ctx.lazy = (bool(dy_lazy), bool(dx_lazy))
         assert not dy_blocked or dy_premasked, "a channel-blocked gradient comes from a SingleConv, i.e. already masked"
         if ystats is None:
             return y, None
@@ -435,6 +443,11 @@ class _SingleConvGCR(torch.autograd.Function):
                                "KEYMORPH_NO_BLOCKED_GRADS=1 to keep every gradient in (N,D,H,W,C)"
                                % (_is_blocked(dy), dy_blocked))
         sd_in = _peek_grad_scale(dy)
+        dy_lazy, dx_lazy = ctx.lazy
+        lazy_tag = getattr(dy, "_kmh_lazy_gn", None)
+        if (lazy_tag is not None and lazy_tag[2] == dy._version) != dy_lazy:
+            raise RuntimeError("keymorph_amd: the first encoder block's lazy GroupNorm-backward hand-off lost its tag (a "
+                               "hook replaced the gradient?) -- set KEYMORPH_NO_LAZY_FIRST=1")
         dy = _prep(dy)
         if ctx.pool:
             # the pooled output's gradient -> the full-resolution one through the winners recorded by the epilogue
@@ -457,9 +470,14 @@ class _SingleConvGCR(torch.autograd.Function):
         first = Cin == 1 and not ctx.needs_input_grad[0] and (Cout <= 16 or CONV_MODE != "f32")
         dscale = (grad_scale(dy) if (_needs_range_scales() and not (first and Cout <= 16)) else None)
         if first:
-            dw, dgamma, dbeta = first_layer_grads(x, scale, shift, mr, gamma, weight, dy, ymask, N, D, H, W, Cout, G,
-                                                  dscale=dscale)
-            return None, dgamma, dbeta, dw, None, None, None, None, None, None
+            if dy_lazy:      # dy = dxn of the next layer, to be combined with that layer's input (= y) on the fly
+                dw, dgamma, dbeta = first_layer_grads(x, scale, shift, mr, gamma, weight, dy, lazy_tag[1], N, D, H, W, Cout,
+                                                      G, dscale=dscale, lazy_c123=lazy_tag[0])
+            else:
+                dw, dgamma, dbeta = first_layer_grads(x, scale, shift, mr, gamma, weight, dy, ymask, N, D, H, W, Cout, G,
+                                                      dscale=dscale)
+            return None, dgamma, dbeta, dw, None, None, None, None, None, None, None, None
+        assert not dy_lazy, "only the first layer's correlation kernel applies a pending GroupNorm backward"
         need_affine = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         need_dxn = ctx.needs_input_grad[0] or need_affine
         # GroupNorm's backward statistics without a pass over dxn and x: sum dxn from the data-gradient launch's
@@ -491,7 +509,12 @@ class _SingleConvGCR(torch.autograd.Function):
             ab = channel_stats(dxn, x, N, V, Cin, only_if=flag)
             check(lib.kmh_gn_bwd_coeffs(_p(ab), _p(gamma), _p(mr), N, Cin, G, float(V), _p(c123), _p(dgamma),
                                         _p(dbeta), _p(flag), _stream()), "kmh_gn_bwd_coeffs")
-            if ctx.needs_input_grad[0]:
+            if ctx.needs_input_grad[0] and dx_lazy:
+                assert x_from_relu and not dx_blocked
+                dx = dxn
+                dx._kmh_lazy_gn = (c123, x, dx._version)      # applied by the first layer's correlation kernel
+                LAZY_STATS["handoffs"] += 1
+            elif ctx.needs_input_grad[0]:
                 # in place on dxn; the (x > 0) mask is the upstream ReLU's backward (x is a ReLU output,
                 # possibly pooled / upsampled / concatenated -- all of which commute with the mask)
                 dx = torch.empty_like(dxn) if dx_blocked else dxn    # another layout cannot be written in place
@@ -501,7 +524,7 @@ class _SingleConvGCR(torch.autograd.Function):
                 if dx_blocked:
                     dx._kmh_blocked = dx._version
                     BLOCKED_STATS["handoffs"] += 1
-        return dx, dgamma, dbeta, dw, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dw, None, None, None, None, None, None, None, None
 
 
 def _up2_forward(skip, low, scale, shift, ascale, weight, N, D, H, W, Cs, Cl, Cout, ystats):
@@ -578,17 +601,15 @@ class _UpCatConvGCR(torch.autograd.Function):
             dy = dzm
         dscale = grad_scale(dy) if _needs_range_scales() else None
         # weight gradient (+ the per-sample fold for GroupNorm).  Skip channels: the 27-tap kernel on `skip`.  Upsampled
-        # channels: dW[tap] = sum_m x_low[m] G[m][tap] with G the 2x2x2 box sums of dz (kmh_up2_box) -- one plain
+        # channels: dW[tap] = sum_m x_low[m] G[m][tap] with G the 2x2x2 box sums of dz (kmh_up2_boxsum) -- one plain
         # matrix product over the low-resolution voxels per sample (1/8 of the multiply-adds; library fp32 GEMM)
         bhat_s = torch.zeros((N, Cs), dtype=torch.float64, device=dy.device)
         dw_s = conv3_wgrad(skip, scale[:, :Cs].contiguous(), shift[:, :Cs].contiguous(), dy, N, D, H, W, Cs, Cout, False,
                            xscale=ctx.ascale, dscale=dscale, fold=(weight[:, :Cs].contiguous(), bhat_s))
         if Cout % 4 == 0 and not os.environ.get("KEYMORPH_NO_UPCONV_WGRAD"):
             Vl = V // 8
-            # one box-filtered copy of dz (2x2x2 sums at every offset, the size of dz): the 27 taps' box sums are its
-            # sub-lattices and are read in place by the product (round 2 wrote them out, 27/8 of dz, and read them back)
-            boxes = _f32((N, 8, D // 2 + 1, H // 2 + 1, W // 2 + 1, Cout), dy.device)
-            check(lib.kmh_up2_box(_p(dy), _p(boxes), N, D // 2, H // 2, W // 2, Cout, _stream()), "kmh_up2_box")
+            boxes = _f32((N, Vl, 27 * Cout), dy.device)
+            check(lib.kmh_up2_boxsum(_p(dy), _p(boxes), N, D // 2, H // 2, W // 2, Cout, _stream()), "kmh_up2_boxsum")
             xl = torch.empty_like(low)
             sc_l, sh_l = scale[:, Cs:].contiguous(), shift[:, Cs:].contiguous()   # named: they must outlive the launch
             check(lib.kmh_norm_apply(_p(low), _p(sc_l), _p(sh_l), N, Vl, Cl, 0, _p(xl), _stream()), "kmh_norm_apply")
@@ -598,7 +619,7 @@ class _UpCatConvGCR(torch.autograd.Function):
             bsc = (dscale * torch.tensor([0.125, 8.0], device=dy.device)) if terms == 2 else None   # sums of 8
             if _lib.profiler.enabled:
                 _lib.profiler.meta = {"flops": 2.0 * 27 * Cl * Cout * N * Vl, "shape": (N, Vl, Cl, 27 * Cout)}
-            check(lib.kmh_up2_wgrad_gemm(_p(xl), _p(boxes), _p(dwn), N, D // 2, H // 2, W // 2, Cl, Cout, terms,
+            check(lib.kmh_up2_wgrad_gemm(_p(xl), _p(boxes), _p(dwn), N, Vl, Cl, 27 * Cout, terms,
                                          _p(ctx.ascale if terms == 2 else None), _p(bsc), _p(gws), _stream()),
                   "kmh_up2_wgrad_gemm")
             del boxes, xl
@@ -662,17 +683,26 @@ def upcat_conv_gcr(skip, low, gamma, beta, weight, num_groups: int, dy_premasked
 
 def single_conv_gcr(x, gamma, beta, weight, num_groups: int, x_from_relu: bool = True,
                     dy_premasked: bool = False, dy_blocked: bool = False, dx_blocked: bool = False,
-                    pool: bool = False) -> Tensor:
+                    pool: bool = False, dy_lazy: bool = False, dx_lazy: bool = False) -> Tensor:
     """dy_premasked: promise that the gradient arriving for the output is already zero wherever the output is
     <= 0 (true when all consumers are SingleConvs with x_from_relu=True).
     pool: return maxpool2 of the output (see conv_pool_ok); the statistics tagged on it are the pooled tensor's."""
     y, ystats = _SingleConvGCR.apply(x, gamma, beta, weight, num_groups, x_from_relu, dy_premasked, dy_blocked,
-                                     dx_blocked, pool)
+                                     dx_blocked, pool, dy_lazy, dx_lazy)
     _tag_stats(y, ystats)       # the next GroupNorm's statistics came with the epilogue
     return y
 
 
 POOL_STATS = {"fused": 0}           # convolutions that pooled in their epilogue (tests)
+LAZY_STATS = {"handoffs": 0}        # GroupNorm backwards applied inside the first layer's correlation kernel (tests)
+
+
+def lazy_first_layer_ok(x, cout1: int) -> bool:
+    """May the SECOND convolution of the first encoder block hand its normalised-input gradient to the FIRST one with
+    GroupNorm's backward still pending?  The first layer must be the 1 -> Cout <= 16 layer with the dedicated kernels
+    and its input must need no gradient (the image)."""
+    return (x.shape[-1] == 1 and cout1 <= 16 and not x.requires_grad and torch.is_grad_enabled()
+            and not os.environ.get("KEYMORPH_NO_LAZY_FIRST"))
 
 
 def conv_pool_ok(N, D, H, W, Cin, Cout) -> bool:

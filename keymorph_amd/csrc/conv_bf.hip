@@ -1242,16 +1242,11 @@ __global__ __launch_bounds__(DUP_TPB, 3) void conv3_up2_dgrad_kernel(
 // the 27-tap weight gradient's images).  Workgroup = 128 x 128 tile of C over one K slab, 64 voxels per step; wave = 64 x 64.
 constexpr int GK = 64;                        // voxels per staging step
 constexpr int GPITCH = GK * 2 + 16;           // bytes per LDS row (64 x 2 B + pad: 9 x 16 B, conflict-free b128 reads)
-// Round 3: B is not a stored (V x J) matrix any more.  Column j = (tap, co); its rows are a sub-lattice of the box-filtered
-// gradient (norm.hip: up2_box_kernel, stored by parity class so that a tap's rows are contiguous), row m of tap
-// (kz, ky, kx) = class (k == 1) at m + (k == 0) per axis, so a thread's column quads fix loop-invariant tap offsets and the
-// row base follows the low voxel (mz, my, mx), which is advanced incrementally (64 voxels per step: no divisions).
 template <int TERMS>
 __global__ __launch_bounds__(256, 2) void up2_wgrad_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                 float* __restrict__ Cp, int V, int Cl, int J, int kslab,
                                                                 int ntn, int ntm, const float* __restrict__ ascale,
-                                                                const float* __restrict__ bscale, int Dl, int Hl, int Wl,
-                                                                int Cout) {
+                                                                const float* __restrict__ bscale) {
   __shared__ __attribute__((aligned(16))) unsigned char sA[TERMS][128 * GPITCH];
   __shared__ __attribute__((aligned(16))) unsigned char sB[TERMS][128 * GPITCH];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -1265,9 +1260,7 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_gemm_kernel(const float* __r
   const float sa = ascale ? ascale[0] : 1.f, sb = bscale ? bscale[0] : 1.f;
   const float desc = (ascale ? ascale[1] : 1.f) * (bscale ? bscale[1] : 1.f);
   const float* An = A + (long long)n * V * Cl;
-  const int HS = Hl + 1, WS = Wl + 1;                                   // extents of one parity sub-tensor of Box
-  const long long sub = (long long)(Dl + 1) * HS * WS * Cout;
-  const float* Bn = B + (long long)n * 8 * sub;
+  const float* Bn = B + (long long)n * V * J;
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1280,43 +1273,18 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_gemm_kernel(const float* __r
   if (k_end > V) k_end = V;
   // staging items: (voxel pair kp, column quad cq) -> 2 float4 loads, 4 packed words per term
   float4 pa[4][2], pb[4][2];
-  // this thread's voxel pair is the same for its 4 items (kp comes from tid alone): (mz, my, mx) of its first voxel, kept
-  // up to date across the steps; and the loop-invariant offsets of its 4 column quads inside the box tensor
-  const int kp_t = (tid >> 2) & 31;
-  int mx, my, mz;
-  {
-    const unsigned k = (unsigned)(k_beg + 2 * kp_t), row = k / (unsigned)Wl;
-    mx = (int)(k - row * (unsigned)Wl); mz = (int)(row / (unsigned)Hl); my = (int)(row - (unsigned)mz * (unsigned)Hl);
-  }
-  long long tapoff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int e = tid + i * 256, cq = (e & 3) + 4 * (e >> 7), cb = n0 + 4 * cq;
-    const int tap = cb / Cout, co = cb - tap * Cout;
-    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-    // tap k reads parity class q = (k == 1) at m' = m + (k == 0), per axis
-    const int cls = ((kz == 1) << 2) | ((ky == 1) << 1) | (kx == 1);
-    tapoff[i] = cb < J ? cls * sub + ((long long)((kz == 0) * HS + (ky == 0)) * WS + (kx == 0)) * Cout + co : 0;
-  }
-  auto box_row = [&](int z, int y, int x) { return (((long long)z * HS + y) * WS + x) * Cout; };
   auto fetch = [&](int k0) {
-    const int k = k0 + 2 * kp_t;
-    // the pair's second voxel: the next one in x, or the first of the next row / plane (odd Wl)
-    int mx1 = mx + 1, my1 = my, mz1 = mz;
-    if (mx1 >= Wl) { mx1 = 0; if (++my1 >= Hl) { my1 = 0; ++mz1; } }
-    const long long r0 = box_row(mz, my, mx), r1 = box_row(mz1, my1, mx1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256, cq = (e & 3) + 4 * (e >> 7);                       // lanes: 4 quads x 16 voxel pairs
+      const int e = tid + i * 256, cq = (e & 3) + 4 * (e >> 7), kp = (e >> 2) & 31;   // lanes: 4 quads x 16 voxel pairs
+      const int k = k0 + 2 * kp;
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       const int ca = m0 + 4 * cq, cb = n0 + 4 * cq;
       pa[i][0] = (k < k_end && ca < Cl) ? *reinterpret_cast<const float4*>(An + (long long)k * Cl + ca) : z4;
       pa[i][1] = (k + 1 < k_end && ca < Cl) ? *reinterpret_cast<const float4*>(An + (long long)(k + 1) * Cl + ca) : z4;
-      pb[i][0] = (k < k_end && cb < J) ? *reinterpret_cast<const float4*>(Bn + r0 + tapoff[i]) : z4;
-      pb[i][1] = (k + 1 < k_end && cb < J) ? *reinterpret_cast<const float4*>(Bn + r1 + tapoff[i]) : z4;
+      pb[i][0] = (k < k_end && cb < J) ? *reinterpret_cast<const float4*>(Bn + (long long)k * J + cb) : z4;
+      pb[i][1] = (k + 1 < k_end && cb < J) ? *reinterpret_cast<const float4*>(Bn + (long long)(k + 1) * J + cb) : z4;
     }
-    mx += GK;                                  // the same pair slot of the next step
-    while (mx >= Wl) { mx -= Wl; if (++my >= Hl) { my = 0; ++mz; } }
   };
   auto commit = [&]() {
 #pragma unroll
@@ -1411,23 +1379,18 @@ KMH_API size_t kmh_up2_wgrad_gemm_ws_bytes(int N, int V, int Cl, int J) {
   return (size_t)N * ns * Cl * J * sizeof(float);
 }
 
-/* C (N, Cl, 27 Cout) = A^T G per sample: A (N, Dl Hl Wl, Cl) the normalised low tensor, G[m][tap] = Box[2m + 1 - k] the
- * box sums read in place from Box (N, 2,2,2, Dl+1, Hl+1, Wl+1, Cout) (kmh_up2_box); Cl % 4 == 0, Cout % 4 == 0; ascale /
- * bscale = {S, 1/S} range scales of A and Box (terms == 2). */
-KMH_API int kmh_up2_wgrad_gemm(const float* A, const float* Box, float* C, int N, int Dl, int Hl, int Wl, int Cl, int Cout,
-                               int terms, const float* ascale, const float* bscale, void* ws, void* stream) {
-  const long long Vll = (long long)Dl * Hl * Wl;
-  if ((Cl & 3) || (Cout & 3) || (terms != 2 && terms != 3) || (terms == 2 && (!ascale || !bscale)) || Vll >= (1ll << 31) ||
-      8ll * (Dl + 1) * (Hl + 1) * (Wl + 1) * Cout >= (1ll << 40))
-    return -22;
-  const int V = (int)Vll, J = 27 * Cout;
+/* C (N, Cl, J) = A^T B per sample: A (N, V, Cl) the normalised low tensor, B (N, V, J) the box sums (kmh_up2_boxsum);
+ * Cl % 4 == 0, J % 4 == 0; ascale / bscale = {S, 1/S} range scales of A and B (terms == 2). */
+KMH_API int kmh_up2_wgrad_gemm(const float* A, const float* B, float* C, int N, int V, int Cl, int J, int terms,
+                               const float* ascale, const float* bscale, void* ws, void* stream) {
+  if ((Cl & 3) || (J & 3) || (terms != 2 && terms != 3) || (terms == 2 && (!ascale || !bscale))) return -22;
   int ks;
   const int ns = up2_wgrad_slabs(V, Cl, J, N, &ks);
   const int ntn = ceil_div(J, 128), ntm = ceil_div(Cl, 128);
   hipStream_t s = (hipStream_t)stream;
   dim3 g(ntn * ntm * ns, 1, N);
-  if (terms == 2) up2_wgrad_gemm_kernel<2><<<g, 256, 0, s>>>(A, Box, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale, Dl, Hl, Wl, Cout);
-  else up2_wgrad_gemm_kernel<3><<<g, 256, 0, s>>>(A, Box, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale, Dl, Hl, Wl, Cout);
+  if (terms == 2) up2_wgrad_gemm_kernel<2><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale);
+  else up2_wgrad_gemm_kernel<3><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale);
   const long long per = (long long)Cl * J;
   int nb = ceil_div(per, 256);
   if (nb > 1024) nb = 1024;

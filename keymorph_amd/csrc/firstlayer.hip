@@ -18,10 +18,15 @@ constexpr int FL_TPB = 320;      // 2 x 144 compute threads (16 co x 9 (kz, ky) 
 constexpr int FL_YR = 8;         // output rows per workgroup
 constexpr int FL_CO = 16;
 
+// c123 (N, Cout, 3) | NULL: GroupNorm's backward of the NEXT layer applied while dz is staged -- dz then holds that layer's
+// normalised-input gradient dxn and dzmask its input (this layer's output y), and the gradient that enters the
+// correlations is [y > 0] (c1 dxn + c2 y + c3): the 256^3 x 16-channel gradient is never written by a separate pass
+// (kmh_gn_bwd_apply: one read of dxn and y, one write) and read back here.
 __global__ __launch_bounds__(FL_TPB) void first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                             const float* __restrict__ dzmask,
                                                             float* __restrict__ partial /* (nblk, Cout, 2, 27) */, int D,
-                                                            int H, int W, int Cout, int ytiles) {
+                                                            int H, int W, int Cout, int ytiles,
+                                                            const float* __restrict__ c123) {
   extern __shared__ __attribute__((aligned(16))) float fsm[];
   const int WP = (W + 3) & ~3;                 // row length rounded to 4
   const int XP = WP + 8;                       // x row pitch: [0..3] left halo (index 3 = x -1), data at 4.., right halo
@@ -62,6 +67,14 @@ __global__ __launch_bounds__(FL_TPB) void first_wgrad_kernel(const float* __rest
   // exposed once per row)
   constexpr int NPRE = 4;                      // float4 items per thread: WP * 4 / FL_TPB <= 4 for W <= 320
   float4 pre[NPRE];
+  // this thread's channel quad is the same for all its items (FL_TPB % 4 == 0): its GroupNorm-backward coefficients
+  float gc[4][3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * (tid & 3) + j;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gc[j][k] = (c123 && c < Cout) ? c123[((long long)n * Cout + c) * 3 + k] : 0.f;
+  }
   auto load_dz = [&](int yy) {
     const int gy = y0 + yy;
 #pragma unroll
@@ -74,6 +87,12 @@ __global__ __launch_bounds__(FL_TPB) void first_wgrad_kernel(const float* __rest
         v = *reinterpret_cast<const float4*>(dn + off);
         if (mn) {
           const float4 m = *reinterpret_cast<const float4*>(mn + off);
+          if (c123) {            // the same expression as gn_bwd_apply_kernel: c1 dxn + c2 x + c3, then the ReLU mask
+            v.x = gc[0][0] * v.x + gc[0][1] * m.x + gc[0][2];
+            v.y = gc[1][0] * v.y + gc[1][1] * m.y + gc[1][2];
+            v.z = gc[2][0] * v.z + gc[2][1] * m.z + gc[2][2];
+            v.w = gc[3][0] * v.w + gc[3][1] * m.w + gc[3][2];
+          }
           if (!(m.x > 0.f)) v.x = 0.f;
           if (!(m.y > 0.f)) v.y = 0.f;
           if (!(m.z > 0.f)) v.z = 0.f;
@@ -104,6 +123,10 @@ __global__ __launch_bounds__(FL_TPB) void first_wgrad_kernel(const float* __rest
       if (xx < W && gy < H && co < Cout) {
         const long long off = (((long long)z * H + gy) * W + xx) * Cout + co;
         v = dn[off];
+        if (mn && c123) {
+          const float* cc = c123 + ((long long)n * Cout + co) * 3;
+          v = cc[0] * v + cc[1] * mn[off] + cc[2];
+        }
         if (mn && !(mn[off] > 0.f)) v = 0.f;
       }
       dst[co * DP + xx] = v;
@@ -353,10 +376,12 @@ KMH_API size_t kmh_conv3d_first_layer_wgrad_ws_bytes(int N, int D, int H, int W,
 }
 
 /* x (N,D,H,W) raw 1-channel input, dz (N,D,H,W,Cout) with Cout <= 16, dzmask like dz or NULL ->
- * rs (N,Cout,2,27): rs[n][co][0][tap] = R, rs[n][co][1][tap] = S  (the input of kmh_conv3d_first_layer_fold) */
-KMH_API int kmh_conv3d_first_layer_wgrad(const float* x, const float* dz, const float* dzmask, float* rs, int N, int D,
-                                         int H, int W, int Cout, void* ws, void* stream) {
-  if (Cout > FL_CO || Cout < 1 || W < 1) return -22;
+ * rs (N,Cout,2,27): rs[n][co][0][tap] = R, rs[n][co][1][tap] = S  (the input of kmh_conv3d_first_layer_fold).
+ * c123 (N,Cout,3) | NULL (needs dzmask): the gradient is [dzmask > 0] (c1 dz + c2 dzmask + c3), i.e. the NEXT layer's
+ * GroupNorm backward (kmh_gn_bwd_apply with relu_mask) applied on the fly to its normalised-input gradient dz. */
+KMH_API int kmh_conv3d_first_layer_wgrad(const float* x, const float* dz, const float* dzmask, const float* c123, float* rs,
+                                         int N, int D, int H, int W, int Cout, void* ws, void* stream) {
+  if (Cout > FL_CO || Cout < 1 || W < 1 || (c123 && !dzmask)) return -22;
   hipStream_t s = (hipStream_t)stream;
   const int WP = (W + 3) & ~3, XP = WP + 8;
   const size_t lds = ((size_t)3 * (FL_YR + 2) * XP + (size_t)2 * FL_CO * (WP + 4)) * sizeof(float);
@@ -364,7 +389,7 @@ KMH_API int kmh_conv3d_first_layer_wgrad(const float* x, const float* dz, const 
   hipError_t e = hipFuncSetAttribute((const void*)first_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int yt = ceil_div(H, FL_YR);
-  first_wgrad_kernel<<<dim3(yt, D, N), FL_TPB, lds, s>>>(x, dz, dzmask, (float*)ws, D, H, W, Cout, yt);
+  first_wgrad_kernel<<<dim3(yt, D, N), FL_TPB, lds, s>>>(x, dz, dzmask, (float*)ws, D, H, W, Cout, yt, c123);
   const int per = Cout * 54;
   first_wgrad_reduce_kernel<<<dim3(ceil_div(per, 4), N), 256, 0, s>>>((const float*)ws, D * yt * FL_XS, per, rs);
   return KMH_LAUNCH_CHECK();

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void tps_assemble_kernel(const float* __restri
 
 // Blocked right-looking LU with partial pivoting, one workgroup per sample.
 // LDS: sP[m][NB+1] (panel, rows k0..n) then sU[NB][ncols] (U12 strip).
-template <int NB>
+template <int NB, bool MFMA64>
 __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aall, int* __restrict__ ipiv_all,
                                                         int* __restrict__ info_all, int n, int lda,
                                                         size_t a_stride) {
@@ -588,7 +588,39 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
           if (r < nb) { sU[r * n + c] = col[r]; A[(size_t)(k0 + r) * lda + k0 + nb + c] = col[r]; }
       }
       __syncthreads();
-      // 6. trailing update A22 -= L21 U12 with 4x4 register tiles
+      // 6. trailing update A22 -= L21 U12.
+      // Round 3: on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), one 16 x 16 tile of A22 per wave and trip: the 4x4
+      // register tiles below read 8 doubles from LDS per 16 multiply-adds and were bound by exactly that (the panel
+      // factorisation, which the round-2 experiments went after, is the smaller part); a matrix-core tile reads 2
+      // per 16.  A / B operands: lane l holds L[r0 + (l & 15)][4 s + (l >> 4)] and U[4 s + (l >> 4)][c0 + (l & 15)];
+      // result register q of lane l is row (l >> 4) + 4 q, column l & 15.
+      if (MFMA64) {
+        typedef double kmh_d4 __attribute__((ext_vector_type(4)));
+        const int t16 = (ncols + 15) / 16;
+        const int li = lane & 15, lk = lane >> 4;
+        for (int tile = wid; tile < t16 * t16; tile += LU_TPB / kWave) {
+          const int r0 = (tile / t16) * 16, c0 = (tile % t16) * 16;
+          kmh_d4 acc = {0.0, 0.0, 0.0, 0.0};
+          double oldv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = r0 + lk + 4 * q, c = c0 + li;
+            oldv[q] = (r < ncols && c < ncols) ? A[(size_t)(k0 + nb + r) * lda + k0 + nb + c] : 0.0;
+          }
+#pragma unroll
+          for (int s4 = 0; s4 < NB / 4; ++s4) {
+            const int k = 4 * s4 + lk;
+            const double a = (r0 + li < ncols && k < nb) ? sP[(nb + r0 + li) * PS + k] : 0.0;
+            const double b = (c0 + li < ncols && k < nb) ? sU[k * n + c0 + li] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = r0 + lk + 4 * q, c = c0 + li;
+            if (r < ncols && c < ncols) A[(size_t)(k0 + nb + r) * lda + k0 + nb + c] = oldv[q] - acc[q];
+          }
+        }
+      } else {
       const int tr = (ncols + 3) / 4, tc = (ncols + 3) / 4;  // A22 is ncols x ncols (square)
       for (int tile = tid; tile < tr * tc; tile += LU_TPB) {
         const int r0 = (tile / tc) * 4, c0 = (tile % tc) * 4;
@@ -615,6 +647,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
           for (int j = 0; j < 4; ++j)
             if (r0 + i < ncols && c0 + j < ncols)
               A[(size_t)(k0 + nb + r0 + i) * lda + k0 + nb + c0 + j] -= acc[i][j];
+      }
       }
     }
     __syncthreads();
@@ -891,193 +924,22 @@ KMH_API size_t kmh_tps_fit_ws_bytes(int N, int T) {
          (size_t)N * n * sizeof(int) + (size_t)N * sizeof(int) + 256;
 }
 
-// Round 3: the same blocked right-looking LU with partial pivoting (same pivot sequence, same arithmetic per element),
-// re-organised around what bounded the kernel above -- dependent chains of L2 round trips and fp64 read-modify-writes in
-// LDS -- for systems of at most LU_TPB rows (one row per thread):
-//   * panel factorisation in REGISTERS: thread r owns one row of the panel (NB doubles) and a position `pos`; pivoting
-//     is a relabelling of positions (row data never moves), the pivot row is broadcast through NB doubles of LDS, the
-//     rank-1 update is NB - j register FMAs: 2 barriers per column, no LDS read-modify-write;
-//   * the row interchanges outside the panel are applied as ONE permutation (<= 2 NB moved rows: every thread issues
-//     all its loads, then a barrier, then all its stores) instead of NB dependent swaps through L2;
-//   * U12 and the trailing update read what they need from global memory BEFORE their arithmetic.
-template <int NB>
-__global__ __launch_bounds__(LU_TPB) void tps_lu_rows_kernel(double* __restrict__ Aall, int* __restrict__ ipiv_all,
-                                                             int* __restrict__ info_all, int n, int lda,
-                                                             size_t a_stride) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int PS = NB + 1;
-  constexpr int NW = LU_TPB / kWave;
-  double* sP = smem;                       // [n][PS]   L21 (and L11) of the current panel, by position
-  double* sU = smem + (size_t)n * PS;      // [NB][n]   U12
-  __shared__ double s_val[2][NW];
-  __shared__ int s_pos[2][NW];
-  __shared__ double s_row[NB];             // the pivot row, columns j..nb-1
-  __shared__ int s_piv[NB];
-  __shared__ int s_from[2 * NB], s_to[2 * NB], s_nmove;
-  double* A = Aall + (size_t)blockIdx.x * a_stride;
-  int* ipiv = ipiv_all + (size_t)blockIdx.x * n;
-  const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1), wid = tid / kWave;
-  int bad = 0;
-
-  for (int k0 = 0; k0 < n; k0 += NB) {
-    const int nb = (n - k0 < NB) ? (n - k0) : NB;
-    const int m = n - k0;
-    const bool mine = tid < m;             // this thread's row: global row k0 + tid before this panel's interchanges
-    // 1. this thread's row of the panel -> registers
-    double row[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) row[c] = (mine && c < nb) ? A[(size_t)(k0 + tid) * lda + k0 + c] : 0.0;
-    int pos = tid;                         // position of the row inside the trailing block (LAPACK's row order)
-    if (tid == 0) s_nmove = 0;
-    // 2. unblocked LU of the panel, rows in registers
-    for (int j = 0; j < nb; ++j) {
-      // pivot: largest |a[., j]| among positions >= j, the smallest position among equals (= the first in row order)
-      double v = -1.0;
-#pragma unroll
-      for (int c = 0; c < NB; ++c) if (c == j) v = fabs(row[c]);
-      double best = (mine && pos >= j) ? v : -1.0;
-      int bp = (mine && pos >= j) ? pos : 0x7fffffff;
-#pragma unroll
-      for (int o = kWave / 2; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(best, o, kWave);
-        const int op = __shfl_xor(bp, o, kWave);
-        if (ov > best || (ov == best && op < bp)) { best = ov; bp = op; }
-      }
-      if (lane == 0) { s_val[j & 1][wid] = best; s_pos[j & 1][wid] = bp; }
-      __syncthreads();
-      best = -1.0; bp = 0x7fffffff;        // every thread finishes the reduction for itself (broadcast reads)
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const double ov = s_val[j & 1][w];
-        const int op = s_pos[j & 1][w];
-        if (ov > best || (ov == best && op < bp)) { best = ov; bp = op; }
-      }
-      if (!(best > 0.0)) { bad = 1; bp = j; }          // singular column: no interchange (as before)
-      const int p = bp;
-      // interchange positions j and p (a relabelling), publish the pivot row
-      if (mine) { if (pos == p) pos = j; else if (pos == j) pos = p; }
-      if (tid == 0) s_piv[j] = p;
-      if (mine && pos == j) {
-#pragma unroll
-        for (int c = 0; c < NB; ++c) if (c >= j) s_row[c] = row[c];
-      }
-      __syncthreads();
-      if (mine && pos > j) {
-        double piv = 0.0;
-#pragma unroll
-        for (int c = 0; c < NB; ++c) if (c == j) piv = s_row[c];
-        const double pinv = 1.0 / piv;
-        double l = 0.0;
-#pragma unroll
-        for (int c = 0; c < NB; ++c) if (c == j) { l = row[c] * pinv; row[c] = l; }
-#pragma unroll
-        for (int c = 0; c < NB; ++c) if (c > j && c < nb) row[c] -= l * s_row[c];
-      }
-      // (s_row is rewritten only after the next column's first barrier; s_val / s_pos alternate)
-    }
-    // 3. pivots (absolute); the panel by final position -> LDS (L11, L21) and global; the moved rows' list
-    if (tid < nb) ipiv[k0 + tid] = k0 + s_piv[tid];
-    if (mine) {
-#pragma unroll
-      for (int c = 0; c < NB; ++c)
-        if (c < nb) { sP[pos * PS + c] = row[c]; A[(size_t)(k0 + pos) * lda + k0 + c] = row[c]; }
-      if (pos != tid) { const int e = atomicAdd(&s_nmove, 1); s_from[e] = tid; s_to[e] = pos; }
-    }
-    __syncthreads();
-    // 4. the same interchanges for the columns outside the panel, as one permutation: all loads, barrier, all stores
-    //    (the first NB moved rows wait in registers, the rest in the U12 buffer, which is idle here)
-    {
-      const int nmove = s_nmove;           // <= 2 nb
-      const int ncol_out = n - nb;         // columns [0, k0) and [k0 + nb, n)
-      double hold[NB];
-      const int c = tid < k0 ? tid : tid + nb;           // this thread's outside column (n <= LU_TPB: at most one)
-      const bool has = tid < ncol_out;
-#pragma unroll
-      for (int e = 0; e < NB; ++e)
-        hold[e] = (has && e < nmove) ? A[(size_t)(k0 + s_from[e]) * lda + c] : 0.0;
-      for (int e = NB; e < nmove; ++e)
-        if (has) sU[(e - NB) * n + c] = A[(size_t)(k0 + s_from[e]) * lda + c];
-      __syncthreads();
-#pragma unroll
-      for (int e = 0; e < NB; ++e)
-        if (has && e < nmove) A[(size_t)(k0 + s_to[e]) * lda + c] = hold[e];
-      for (int e = NB; e < nmove; ++e)
-        if (has) A[(size_t)(k0 + s_to[e]) * lda + c] = sU[(e - NB) * n + c];
-    }
-    __syncthreads();  // interchanges visible (same workgroup, global memory) before U12 reads
-    const int ncols = n - k0 - nb;
-    if (ncols > 0) {
-      // 5. U12 = L11^-1 A12, one thread per column
-      for (int c = tid; c < ncols; c += LU_TPB) {
-        double col[NB];
-#pragma unroll
-        for (int r = 0; r < NB; ++r) col[r] = (r < nb) ? A[(size_t)(k0 + r) * lda + k0 + nb + c] : 0.0;
-#pragma unroll
-        for (int r = 1; r < NB; ++r) {
-          double a = col[r];
-#pragma unroll
-          for (int k = 0; k < r; ++k) a -= sP[r * PS + k] * col[k];
-          col[r] = a;
-        }
-#pragma unroll
-        for (int r = 0; r < NB; ++r)
-          if (r < nb) { sU[r * n + c] = col[r]; A[(size_t)(k0 + r) * lda + k0 + nb + c] = col[r]; }
-      }
-      __syncthreads();
-      // 6. trailing update A22 -= L21 U12 with 4x4 register tiles; the tile of A22 is fetched before the products
-      const int tr = (ncols + 3) / 4, tc = (ncols + 3) / 4;  // A22 is ncols x ncols (square)
-      for (int tile = tid; tile < tr * tc; tile += LU_TPB) {
-        const int r0 = (tile / tc) * 4, c0 = (tile % tc) * 4;
-        double old[4][4], acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            acc[i][jj] = 0.0;
-            old[i][jj] = (r0 + i < ncols && c0 + jj < ncols) ? A[(size_t)(k0 + nb + r0 + i) * lda + k0 + nb + c0 + jj] : 0.0;
-          }
-#pragma unroll 4
-        for (int k = 0; k < nb; ++k) {
-          double l[4], u[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) l[i] = (r0 + i < ncols) ? sP[(nb + r0 + i) * PS + k] : 0.0;
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) u[jj] = (c0 + jj < ncols) ? sU[k * n + c0 + jj] : 0.0;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[i][jj] += l[i] * u[jj];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            if (r0 + i < ncols && c0 + jj < ncols)
-              A[(size_t)(k0 + nb + r0 + i) * lda + k0 + nb + c0 + jj] = old[i][jj] - acc[i][jj];
-      }
-    }
-    __syncthreads();
-  }
-  if (tid == 0) info_all[blockIdx.x] = bad;
-}
-
 template <int NB>
 static int launch_lu(const FitWs& f, int N, int n, hipStream_t s) {
   const size_t lds = ((size_t)n * (NB + 1) + (size_t)NB * n) * sizeof(double);
   if (lds > 160 * 1024 - 1024) return -22;
-  static const bool old_lu = getenv("KEYMORPH_TPS_LU_OLD") != nullptr;      // A/B measurements only
-  if (n <= LU_TPB && !old_lu) {            // one row per thread: the register-panel kernel
-    hipError_t e = hipFuncSetAttribute((const void*)tps_lu_rows_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  static const bool valu_trailing = getenv("KEYMORPH_TPS_LU_VALU") != nullptr;      // A/B measurements only
+  if (valu_trailing) {
+    hipError_t e = hipFuncSetAttribute((const void*)tps_lu_kernel<NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return (int)e;
-    tps_lu_rows_kernel<NB><<<N, LU_TPB, lds, s>>>(f.A, f.ipiv, f.info, n, f.lda, f.a_stride);
+    tps_lu_kernel<NB, false><<<N, LU_TPB, lds, s>>>(f.A, f.ipiv, f.info, n, f.lda, f.a_stride);
     return KMH_LAUNCH_CHECK();
   }
-  hipError_t e = hipFuncSetAttribute((const void*)tps_lu_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute((const void*)tps_lu_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
-  tps_lu_kernel<NB><<<N, LU_TPB, lds, s>>>(f.A, f.ipiv, f.info, n, f.lda, f.a_stride);
+  tps_lu_kernel<NB, true><<<N, LU_TPB, lds, s>>>(f.A, f.ipiv, f.info, n, f.lda, f.a_stride);
   return KMH_LAUNCH_CHECK();
 }
 

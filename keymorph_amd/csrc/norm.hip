@@ -667,54 +667,67 @@ KMH_API int kmh_gn_bwd_apply(const float* dxn, const float* x, const float* c123
 // ---------------------------------------------------------------------------------------------------------------
 // Box sums for the weight gradient of a 3x3x3 convolution over a nearest-x2 upsampled tensor: with x_up[v] = x_low[v / 2],
 //   dW[tap][ci][co] = sum_v x_up[v + tap][ci] dz[v][co] = sum_m x_low[m][ci] * G[m][tap][co],
-//   G[m][tap][co]   = sum of dz over the 2 x 2 x 2 voxels v with (v + tap) / 2 == m, i.e. per axis v in {2m + 1 - k, 2m + 2 - k}
-//                     for tap index k = tap + 1 in {0, 1, 2},
-// so the correlation becomes ONE plain matrix product over the low-resolution voxels (1/8 of the multiply-adds).
-// Round 3: G is never formed.  All 27 G[., tap] are sub-lattices of ONE box-filtered tensor
-//   Box[u] = sum_{d in {0,1}^3} dz[u + d]   (zero outside the volume),  u in [-1, 2D - 1] per axis,
-//   G[m][tap] = Box[2m + 1 - k]  per axis,
-// so this kernel writes Box -- the size of dz instead of 27/8 of it -- and the matrix product (csrc/conv_bf.hip:
-// up2_wgrad_gemm_kernel) reads its B operand's rows from the sub-lattice of its tap.
-// Layout: the 8 parity classes of u + 1 are stored as 8 separate sub-tensors,
-//   Box[n][qz][qy][qx][mz'][my'][mx'][co],  u + 1 = 2 m' + q per axis,  m' in [0, Dl] (extent Dl + 1),
-// so that the rows one tap reads for consecutive low voxels are CONTIGUOUS (tap k: q = (k == 1), m' = m + (k == 0)); a
-// first version with one interleaved (2D+1)^3 tensor made the product 1.7x slower (every tap strides over every
-// second voxel, row and plane).
-// Thread = (box voxel, channel quad): 8 loads of 16 bytes that neighbouring threads share through L1 / L2, one store.
-__global__ __launch_bounds__(256) void up2_box_kernel(const float* __restrict__ dz, float* __restrict__ box, int D, int H,
-                                                      int W, int C4) {
+//   G[m][tap][co]   = sum of dz over the 2 x 2 x 2 voxels v with (v + tap) / 2 == m, i.e. per axis v in {2m - tap, 2m + 1 - tap}
+// so the correlation becomes ONE plain matrix product over the low-resolution voxels (1/8 of the multiply-adds).  This
+// kernel forms G (N, V_low, 27, Cout) from dz (N, 2Dl, 2Hl, 2Wl, Cout): thread = (low voxel, channel quad), the 4 x 4 x 4
+// window is streamed once and reduced separably (x pairs, then y pairs, then z pairs).
+__global__ __launch_bounds__(256, 3) void up2_boxsum_kernel(const float* __restrict__ dz, float* __restrict__ G, int Dl,
+                                                            int Hl, int Wl, int Cout) {
+  // thread = (low voxel, z tap, channel quad): 2 of the window's 4 planes, 9 outputs -- ~100 registers instead of 256
   const int n = blockIdx.y;
-  const int DS = D / 2 + 1, HS = H / 2 + 1, WS = W / 2 + 1;           // extents of one parity sub-tensor
-  const long long sub = (long long)DS * HS * WS * C4;
-  const long long total = 8 * sub;
-  const float4* dn = reinterpret_cast<const float4*>(dz) + (long long)n * D * H * W * C4;
-  float4* bn = reinterpret_cast<float4*>(box) + (long long)n * total;
+  const int cq = Cout >> 2;
+  const long long total = (long long)Dl * Hl * Wl * 3 * cq;
+  const int D = 2 * Dl, H = 2 * Hl, W = 2 * Wl;
+  const float* dn = dz + (long long)n * D * H * W * Cout;
+  float* gn = G + (long long)n * Dl * Hl * Wl * 27 * Cout;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const int cls = (int)(e / sub);
-    long long v = e - cls * sub;
-    const int q = (int)(v % C4); v /= C4;
-    const int mx = (int)(v % WS), my = (int)((v / WS) % HS), mz = (int)(v / ((long long)WS * HS));
-    const int ux = 2 * mx + (cls & 1) - 1, uy = 2 * my + ((cls >> 1) & 1) - 1, uz = 2 * mz + (cls >> 2) - 1;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int q = (int)(e % cq);
+    const int kz = (int)((e / cq) % 3);
+    const long long m = e / (3 * cq);
+    const int mx = (int)(m % Wl), my = (int)((m / Wl) % Hl), mz = (int)(m / ((long long)Wl * Hl));
+    float4 Y[3][3];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      const int z = uz + (d >> 2), y = uy + ((d >> 1) & 1), x = ux + (d & 1);
-      if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
-        const float4 t = dn[(((long long)z * H + y) * W + x) * C4 + q];
-        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    for (int a = 0; a < 9; ++a) (&Y[0][0])[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // window index i = u - (2m - 1) in 0..3 per axis; tap k (offset k - 1) sums i in {2 - k, 3 - k}
+#pragma unroll
+    for (int dzp = 0; dzp < 2; ++dzp) {
+      const int uz = 2 * mz - 1 + (2 - kz) + dzp;
+#pragma unroll
+      for (int iy = 0; iy < 4; ++iy) {
+        const int uy = 2 * my - 1 + iy;
+        float4 a4[4];
+#pragma unroll
+        for (int ix = 0; ix < 4; ++ix) {
+          const int ux = 2 * mx - 1 + ix;
+          a4[ix] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if ((unsigned)ux < (unsigned)W && (unsigned)uy < (unsigned)H && (unsigned)uz < (unsigned)D)
+            a4[ix] = *reinterpret_cast<const float4*>(dn + (((long long)uz * H + uy) * W + ux) * Cout + 4 * q);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float4 u = a4[2 - kx], v = a4[3 - kx];
+          const float4 xs = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+            if (iy == 2 - ky || iy == 3 - ky) {
+              Y[ky][kx].x += xs.x; Y[ky][kx].y += xs.y; Y[ky][kx].z += xs.z; Y[ky][kx].w += xs.w;
+            }
+        }
       }
     }
-    bn[e] = s;
+    float* o = gn + (m * 27 + kz * 9) * Cout + 4 * q;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) *reinterpret_cast<float4*>(o + (long long)a * Cout) = (&Y[0][0])[a];
   }
 }
 
-/* Box (N, 2, 2, 2, Dl+1, Hl+1, Wl+1, Cout) from dz (N, 2Dl, 2Hl, 2Wl, Cout), Cout % 4 == 0:
- * Box[n][qz][qy][qx][mz][my][mx] = the sum of dz over the 2 x 2 x 2 voxels at u + {0,1}^3 inside the volume, with
- * u + 1 = 2 m + q per axis, i.e. u in [-1, 2D] (see above). */
-KMH_API int kmh_up2_box(const float* dz, float* box, int N, int Dl, int Hl, int Wl, int Cout, void* stream) {
-  if ((Cout & 3) || N <= 0 || Dl <= 0 || Hl <= 0 || Wl <= 0) return -22;
-  const long long total = 8ll * (Dl + 1) * (Hl + 1) * (Wl + 1) * (Cout / 4);
-  up2_box_kernel<<<dim3(stream_blocks(total), N), 256, 0, (hipStream_t)stream>>>(dz, box, 2 * Dl, 2 * Hl, 2 * Wl, Cout / 4);
+/* G (N, Dl*Hl*Wl, 27, Cout) from dz (N, 2Dl, 2Hl, 2Wl, Cout), Cout % 4 == 0 (see the kernel comment): the weight gradient
+ * of a 3x3x3 convolution with respect to nearest-x2 upsampled input channels is then x_low^T (Cl x V_low) times G
+ * (V_low x 27 Cout) per sample -- one plain matrix product (the host uses the library GEMM). */
+KMH_API int kmh_up2_boxsum(const float* dz, float* G, int N, int Dl, int Hl, int Wl, int Cout, void* stream) {
+  if (Cout & 3) return -22;
+  const long long total = (long long)Dl * Hl * Wl * 3 * (Cout / 4);
+  up2_boxsum_kernel<<<dim3(stream_blocks(total), N), 256, 0, (hipStream_t)stream>>>(dz, G, Dl, Hl, Wl, Cout);
   return KMH_LAUNCH_CHECK();
 }
 

@@ -789,3 +789,64 @@ def test_fused_upsample_concat_conv_applies_its_own_relu_mask():
             close(ga.double(), r.grad, 1e-4 * float(r.grad.abs().max()), 1e-3)
     finally:
         B.set_conv_mode(old)
+
+
+@pytest.mark.parametrize("dims", [(8, 16, 64), (7, 9, 33)])
+def test_first_block_lazy_groupnorm_backward_handoff(dims, monkeypatch):
+    """The first encoder block on an image: the second convolution hands its normalised-input gradient to the first
+    layer's correlation kernel with GroupNorm's backward still pending (applied while the kernel stages the gradient, so
+    the full-resolution 16-channel gradient is never written by a separate pass).  Every parameter gradient must equal
+    the plain route's (the same expression c1 dxn + c2 y + c3 under the same ReLU mask, evaluated in another kernel)
+    and PyTorch's."""
+    from keymorph_amd import backbone_ops as B
+    from keymorph_amd.unet3d.model import DoubleConv
+    old = B.CONV_MODE
+    try:
+        B.set_conv_mode("f16x3")
+        torch.manual_seed(11)
+        blk = DoubleConv(1, 32, encoder=True, num_groups=8, first_layer=True).to(DEV)
+        img = torch.rand(2, *dims, 1, generator=gen(12)).to(DEV)
+        cot = torch.randn(2, *dims, 32, generator=gen(13)).to(DEV)
+
+        def run():
+            for p_ in blk.parameters():
+                p_.grad = None
+            y = blk(img, True)
+            (y * (cot * (y.detach() > 0))).sum().backward()
+            return y.detach().clone(), [p_.grad.clone() for p_ in blk.parameters()]
+
+        before = B.LAZY_STATS["handoffs"]
+        y1, g1 = run()
+        assert B.LAZY_STATS["handoffs"] == before + 1, "the lazy hand-off did not run"
+        monkeypatch.setenv("KEYMORPH_NO_LAZY_FIRST", "1")
+        y0, g0 = run()
+        assert B.LAZY_STATS["handoffs"] == before + 1
+        assert torch.equal(y1, y0)
+        for a, r in zip(g1, g0):
+            close(a, r, 2e-6 * float(r.abs().max()), 1e-5)
+        # and against PyTorch (fp64) on the same masked cotangent
+        ref = torch.nn.Sequential(torch.nn.GroupNorm(1, 1), torch.nn.Conv3d(1, 16, 3, padding=1, bias=False), torch.nn.ReLU(),
+                                  torch.nn.GroupNorm(8, 16), torch.nn.Conv3d(16, 32, 3, padding=1, bias=False),
+                                  torch.nn.ReLU()).double()
+        sd = blk.state_dict()
+        ref[0].load_state_dict({"weight": sd["SingleConv1.groupnorm.weight"].double().cpu(),
+                                "bias": sd["SingleConv1.groupnorm.bias"].double().cpu()})
+        ref[1].load_state_dict({"weight": sd["SingleConv1.conv.weight"].double().cpu()})
+        ref[3].load_state_dict({"weight": sd["SingleConv2.groupnorm.weight"].double().cpu(),
+                                "bias": sd["SingleConv2.groupnorm.bias"].double().cpu()})
+        ref[4].load_state_dict({"weight": sd["SingleConv2.conv.weight"].double().cpu()})
+        yr = ref(ncdhw(img.cpu().double()))
+        (yr * ncdhw((cot * (y1 > 0)).cpu().double())).sum().backward()
+        close(ncdhw(y1), yr, 2e-5, 1e-4)
+        # (the first layer's one-element GroupNorm weight / bias are sums over the whole volume that cancel to ~0: they
+        # are compared between the two routes above, not against fp64 at a relative bar)
+        names = ["SingleConv1.conv.weight", "SingleConv2.groupnorm.weight", "SingleConv2.groupnorm.bias",
+                 "SingleConv2.conv.weight"]
+        refg = {"SingleConv1.groupnorm.weight": ref[0].weight.grad, "SingleConv1.groupnorm.bias": ref[0].bias.grad,
+                "SingleConv1.conv.weight": ref[1].weight.grad, "SingleConv2.groupnorm.weight": ref[3].weight.grad,
+                "SingleConv2.groupnorm.bias": ref[3].bias.grad, "SingleConv2.conv.weight": ref[4].weight.grad}
+        got = dict(zip([k for k, _ in blk.named_parameters()], g1))
+        for k in names:
+            close(got[k], refg[k], 3e-4 * float(refg[k].abs().max()) + 1e-6, 1e-3)
+    finally:
+        B.set_conv_mode(old)
