@@ -822,8 +822,9 @@ def test_first_block_lazy_groupnorm_backward_handoff(dims, monkeypatch):
         y0, g0 = run()
         assert B.LAZY_STATS["handoffs"] == before + 1
         assert torch.equal(y1, y0)
-        for a, r in zip(g1, g0):
-            close(a, r, 2e-6 * float(r.abs().max()), 1e-5)
+        for (k, _), a, r in zip(blk.named_parameters(), g1, g0):
+            err = float((a - r).abs().max()) / (float(r.abs().max()) + 1e-30)
+            assert err < 5e-6, ("lazy vs plain route", k, err)
         # and against PyTorch (fp64) on the same masked cotangent
         ref = torch.nn.Sequential(torch.nn.GroupNorm(1, 1), torch.nn.Conv3d(1, 16, 3, padding=1, bias=False), torch.nn.ReLU(),
                                   torch.nn.GroupNorm(8, 16), torch.nn.Conv3d(16, 32, 3, padding=1, bias=False),
@@ -847,6 +848,9 @@ def test_first_block_lazy_groupnorm_backward_handoff(dims, monkeypatch):
                 "SingleConv2.groupnorm.bias": ref[3].bias.grad, "SingleConv2.conv.weight": ref[4].weight.grad}
         got = dict(zip([k for k, _ in blk.named_parameters()], g1))
         for k in names:
-            close(got[k], refg[k], 3e-4 * float(refg[k].abs().max()) + 1e-6, 1e-3)
+            # relative L2: the HIDDEN activation's ReLU mask is each implementation's own, and a pre-activation within
+            # rounding of zero flips it (one flip moves single weight-gradient entries by ~1e-2 of their size)
+            a, r = got[k].detach().cpu().double(), refg[k].double()
+            assert float((a - r).norm() / r.norm()) < 5e-3, k
     finally:
         B.set_conv_mode(old)
