@@ -398,6 +398,22 @@ def main():
             gb = a.size ** 3 * (12 + 8 * C) / 1e9
             out[f"C{C}"] = {"ms": ms, "algorithmic_GB": gb, "GBps": gb / ms * 1e3, "frac_of_hbm_peak": gb / ms * 1e3 / HBM_PEAK_GBS}
             del vol
+        # calibration: a plain device copy moving the same number of bytes as the C = 1 warp (half read, half written)
+        nb = a.size ** 3 * 20 // 2
+        src = torch.empty(nb // 4, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        out["copy_same_bytes"] = {"ms": ms, "GB": 2 * nb / 1e9, "GBps": 2 * nb / ms / 1e6,
+                                  "note": "torch copy_ of the C = 1 warp's algorithmic byte count: what a streaming kernel "
+                                          "reaches on this chip at this size"}
         extra["align_img_standalone"] = out
 
     def convnet_leg():
