@@ -149,6 +149,29 @@ class KeyMorph(nn.Module):
             points_m = self.get_keypoints(img_m)
         keypoint_extract_time = time.time() - start_time
 
+        # Evaluation with several thin-plate-spline types (pairwise_register_eval.py:116-171 passes a list): every fit the
+        # loop below would launch one after the other -- (lambda, direction) per type, one CU each -- is solved in ONE
+        # batched launch up front; the aligners find their coefficients already in place.
+        prefit = {}
+        tps_types = [t for t in transform_type if t.startswith("tps") and not isinstance(str_or_float(t[4:]), str)]
+        # (numeric lambdas only: "uniform" / "loguniform" draw random values, which must be drawn once, in the loop)
+        if (not self.training and not torch.is_grad_enabled() and not self.align_keypoints_in_real_world_coords
+                and len(tps_types) * (2 if return_aligned_points else 1) > 1):
+            from . import ops
+            n = len(img_f)
+            ctrl, tgt, lam = [], [], []
+            for t in tps_types:
+                lm = self._convert_tps_lmbda(n, str_or_float(t[4:])).to(img_f.device).float()
+                ctrl.append(points_f); tgt.append(points_m); lam.append(lm)             # inverse map: fixed -> moving
+                if return_aligned_points:
+                    ctrl.append(points_m); tgt.append(points_f); lam.append(lm)         # forward map: moving -> fixed
+            theta = ops.tps_fit(torch.cat(ctrl), torch.cat(tgt), torch.cat(lam),
+                                None if weights is None else weights.repeat(len(ctrl), 1))
+            per = 2 if return_aligned_points else 1
+            for i, t in enumerate(tps_types):
+                prefit[t] = (theta[(per * i) * n:(per * i + 1) * n],
+                             theta[(per * i + 1) * n:(per * i + 2) * n] if return_aligned_points else None)
+
         result_dict = {}
         for align_type_str in transform_type:
             start_time = time.time()
@@ -166,6 +189,8 @@ class KeyMorph(nn.Module):
                 if weights is not None:      # model.py:221-222: the weights follow their keypoints
                     weights = weights[:, idx]
             aligner = self._make_aligner(align_type, points_m, points_f, tps_lmbda, weights, aff)
+            if align_type_str in prefit:
+                aligner._inverse_theta, aligner.theta = prefit[align_type_str]
             grid = aligner.get_flow_field(img_f.shape, compute_on_subgrids=not self.training)
             if return_aligned_points:
                 points_a = aligner.get_forward_transformed_points(points_m)
