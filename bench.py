@@ -504,6 +504,12 @@ def main():
                 "backend": torch.distributed.get_backend() if world > 1 else None,
                 "pair_seeds_rank0": [100 * rank + i for i in range(a.pairs_per_gpu)],
                 "pair_seed_rule": "rank r owns pairs 100 r + i, i < pairs-per-gpu (synthetic.make_pair seeds)",
+                "parity": "keypoints / grid / warped volume / MSE / Dice within 1e-4 of the reference arithmetic wherever the "
+                          "problem is well conditioned (tests/: affine, rigid, tps_lambda >= 0.1; 120x120x90 ragged and 128^3 "
+                          "whole-path runs at 1e-6..4e-6).  THIS configuration (512 keypoints, lambda = 0, random-init clumped "
+                          "keypoints) has cond(A) ~ 1e6: the reference's own fp32 path is 3.8e-4 from the fp64 truth on the "
+                          "grid there, and parity is |ours - truth| <= 1.25 |reference - truth| "
+                          "(tests/test_ops_gpu.py::test_tps_k512_lambda0_vs_truth), not a plain 1e-4 statement",
                 "arithmetic": {"f16x3": "conv: fp32 operands range-scaled by 2^k and split into fp16 hi+lo, 3 MFMA products, "
                                         "fp32 accumulate (5e-7 vs fp64, like fp32 MFMA); the fused 1x1x1 head uses the same scheme",
                                "bf16x6": "fp32 operands split into bf16 hi+mid+lo, 6 MFMA products, fp32 accumulate",

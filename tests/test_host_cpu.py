@@ -297,3 +297,35 @@ def test_use_amp_is_accepted_but_warns():
     with pytest.warns(UserWarning, match="use_amp"):
         km = KeyMorph(nn.Identity(), 4, 3, use_amp=True)
     assert km.use_amp is True
+
+
+def test_flat_params_gathers_gradients():
+    """FlatParams.zero_grad() drops the gradients, autograd assigns fresh tensors, and the first access to .grad gathers
+    them into the flat buffer (one multi-tensor copy) and re-points every p.grad at its slice: same observable
+    behaviour as accumulating into views -- incl. accumulation over two backward passes and parameters that got none."""
+    import torch.nn as nn
+    torch.manual_seed(0)
+    lin1, lin2, unused = nn.Linear(3, 4), nn.Linear(4, 2), nn.Linear(2, 2)
+    params = list(lin1.parameters()) + list(lin2.parameters()) + list(unused.parameters())
+    flat = parallel.FlatParams(params)
+    x = torch.randn(5, 3)
+
+    def loss():
+        return lin2(torch.tanh(lin1(x))).pow(2).sum()
+
+    ref = torch.autograd.grad(loss(), list(lin1.parameters()) + list(lin2.parameters()))
+    flat.zero_grad()
+    assert all(p.grad is None for p in params)
+    loss().backward()
+    g = flat.grad                                          # gathers
+    o = 0
+    for p, r in zip(params[:4], ref):
+        assert torch.allclose(g[o:o + p.numel()].view_as(p), r) and p.grad.data_ptr() == g[o:o + p.numel()].data_ptr()
+        o += p.numel()
+    assert float(g[o:].abs().max()) == 0.0                 # the unused module's slices are zero
+    loss().backward()                                      # no zero_grad: accumulates into the flat views
+    assert torch.allclose(flat.grad[:params[0].numel()].view_as(params[0]), 2 * ref[0])
+    assert flat.allreduce_grads() == 1.0
+    flat.zero_grad()
+    loss().backward()
+    assert torch.allclose(flat.grad[:params[0].numel()].view_as(params[0]), ref[0])
