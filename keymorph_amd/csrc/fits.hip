@@ -489,7 +489,6 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
   __shared__ double s_val[LU_TPB / kWave];
   __shared__ int s_idx[LU_TPB / kWave];
   __shared__ int s_piv[NB];
-  __shared__ int s_tpos[2 * NB], s_tcur[2 * NB], s_from[2 * NB], s_to[2 * NB], s_nmove;
   double* A = Aall + (size_t)blockIdx.x * a_stride;
   int* ipiv = ipiv_all + (size_t)blockIdx.x * n;
   const int tid = threadIdx.x;
@@ -551,38 +550,17 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
       }
       __syncthreads();
     }
-    // 3. record pivots (absolute) and apply the swaps to the columns outside the panel.
-    // Round 3: as ONE permutation.  The nb sequential interchanges touch at most 2 nb rows; thread 0 composes them on that
-    // small set, and every thread then loads all moved rows' values of its column (independent loads: one L2 round trip)
-    // before it stores any -- instead of nb dependent load / store round trips through L2 per column.
+    // 3. record pivots (absolute) and apply the swaps to the columns outside the panel
     if (tid < nb) ipiv[k0 + tid] = k0 + s_piv[tid];
-    if (tid == 0) {
-      int cnt = nb;
-      for (int j = 0; j < nb; ++j) { s_tpos[j] = j; s_tcur[j] = j; }
+    for (int c = tid; c < n; c += LU_TPB) {
+      if (c >= k0 && c < k0 + nb) continue;
       for (int j = 0; j < nb; ++j) {
         const int p = s_piv[j];
-        if (p == j) continue;
-        int ip = -1;
-        for (int i = 0; i < cnt; ++i) if (s_tpos[i] == p) { ip = i; break; }
-        if (ip < 0) { ip = cnt; s_tpos[cnt] = p; s_tcur[cnt] = p; ++cnt; }
-        const int t = s_tcur[j]; s_tcur[j] = s_tcur[ip]; s_tcur[ip] = t;
-      }
-      int nm = 0;
-      for (int i = 0; i < cnt; ++i)
-        if (s_tcur[i] != s_tpos[i]) { s_from[nm] = s_tcur[i]; s_to[nm] = s_tpos[i]; ++nm; }
-      s_nmove = nm;
-    }
-    __syncthreads();
-    {
-      const int nmove = s_nmove;
-      for (int c = tid; c < n; c += LU_TPB) {
-        if (c >= k0 && c < k0 + nb) continue;
-        double hold[2 * NB];
-#pragma unroll
-        for (int e = 0; e < 2 * NB; ++e) hold[e] = e < nmove ? A[(size_t)(k0 + s_from[e]) * lda + c] : 0.0;
-#pragma unroll
-        for (int e = 0; e < 2 * NB; ++e)
-          if (e < nmove) A[(size_t)(k0 + s_to[e]) * lda + c] = hold[e];
+        if (p != j) {
+          const double t = A[(size_t)(k0 + j) * lda + c];
+          A[(size_t)(k0 + j) * lda + c] = A[(size_t)(k0 + p) * lda + c];
+          A[(size_t)(k0 + p) * lda + c] = t;
+        }
       }
     }
     // 4. panel back to global
