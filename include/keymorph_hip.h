@@ -297,6 +297,12 @@ int kmh_maxpool3d_fwd(const float* x, float* y, unsigned char* argmax, int N, in
  * (U-Net skip connection; may alias dx).  Odd D/H/W: the caller pre-fills the window-less trailing planes. */
 int kmh_maxpool3d_bwd(const float* x, const unsigned char* argmax, const float* dy, const float* add, int add_cstride,
                       float* dx, int N, int D, int H, int W, int C, int out_blocked, void* stream);
+/* dx = scatter(dy) + [x > 0] (c1 dxn + c2 x + c3): the pooling backward summed with the skip connection's gradient whose
+ * GroupNorm backward (c123 (N,C,3), kmh_gn_bwd_apply's coefficients) is applied on the fly -- autograd of max_pool3d plus
+ * the decoder's skip (keymorph/unet3d/buildingblocks.py:363, 471-475) in one pass; even D, H, W, C % 4 == 0, dense
+ * tensors; dx_scale2 | NULL receives {S, 1/S} for max |dx| */
+int kmh_maxpool3d_bwd_lazy(const unsigned char* argmax, const float* dy, const float* dxn, const float* x, const float* c123,
+                           float* dx, int N, int D, int H, int W, int C, float* dx_scale2, void* stream);
 /* decoder join: out = cat(skip, nearest_upsample(low -> skip size)) (buildingblocks.py:471-475,568-582) */
 int kmh_upcat_fwd(const float* skip, const float* low, float* out, int N, int D, int H, int W, int Cs, int Dl,
                   int Hl, int Wl, int Cl, void* stream);

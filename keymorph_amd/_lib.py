@@ -96,6 +96,7 @@ PROTOS = {
     "kmh_norm_apply": (_i, [_f, _f, _f, _i, _ll, _i, _i, _f, _f]),
     "kmh_maxpool3d_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "kmh_maxpool3d_bwd": (_i, [_f, _f, _f, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f]),
+    "kmh_maxpool3d_bwd_lazy": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f]),
     "kmh_upcat_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f]),
     "kmh_upcat_bwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f]),
     "kmh_layout_convert": (_i, [_f, _f, _i, _ll, _i, _i, _f]),

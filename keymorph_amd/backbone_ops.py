@@ -569,7 +569,11 @@ class _UpCatConvGCR(torch.autograd.Function):
     children, i.e. interpolate's backward), and GroupNorm's backward is applied to the two halves separately."""
 
     @staticmethod
-    def forward(ctx, skip, low, gamma, beta, weight, num_groups, dy_premasked):
+    def forward(ctx, skip, low, gamma, beta, weight, num_groups, dy_premasked, dskip_lazy=False):
+        """dskip_lazy: `skip` is the second output of pool_fork (its gradient goes to _PoolFork.backward and nowhere else):
+        the skip half's normalised-input gradient is returned with GroupNorm's backward pending, and the pooling backward
+        applies it while it sums the two gradients (kmh_maxpool3d_bwd_lazy)."""
+        ctx.dskip_lazy = bool(dskip_lazy)
         skip, low, gamma, beta, weight = _prep(skip), _prep(low), _prep(gamma), _prep(beta), _prep(weight)
         N, D, H, W, Cs = skip.shape
         Cl, Cout = low.shape[-1], weight.shape[0]
@@ -662,7 +666,11 @@ class _UpCatConvGCR(torch.autograd.Function):
         sc_s = torch.zeros(2, dtype=torch.float32, device=dy.device) if want else None
         sc_l = torch.zeros(2, dtype=torch.float32, device=dy.device) if want else None
         dskip = dlow = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.dskip_lazy:
+            dskip = dxn_s
+            dskip._kmh_lazy_gn = (c_s, skip, dskip._version)       # applied by _PoolFork.backward
+            LAZY_STATS["handoffs"] += 1
+        elif ctx.needs_input_grad[0]:
             check(lib.kmh_gn_bwd_apply(_p(dxn_s), _p(skip), _p(c_s), N, V, Cs, 1, 0, _p(dxn_s), _p(sc_s), 0, _stream()),
                   "kmh_gn_bwd_apply")
             dskip = dxn_s
@@ -672,11 +680,12 @@ class _UpCatConvGCR(torch.autograd.Function):
                                        _stream()), "kmh_gn_bwd_apply")
             dlow = dsum_l
             _tag_grad_scale(dlow, sc_l)
-        return dskip, dlow, dgamma, dbeta, dw, None, None
+        return dskip, dlow, dgamma, dbeta, dw, None, None, None
 
 
-def upcat_conv_gcr(skip, low, gamma, beta, weight, num_groups: int, dy_premasked: bool = False) -> Tensor:
-    y, ystats = _UpCatConvGCR.apply(skip, low, gamma, beta, weight, num_groups, dy_premasked)
+def upcat_conv_gcr(skip, low, gamma, beta, weight, num_groups: int, dy_premasked: bool = False,
+                   dskip_lazy: bool = False) -> Tensor:
+    y, ystats = _UpCatConvGCR.apply(skip, low, gamma, beta, weight, num_groups, dy_premasked, dskip_lazy)
     _tag_stats(y, ystats)
     return y
 
@@ -695,6 +704,13 @@ def single_conv_gcr(x, gamma, beta, weight, num_groups: int, x_from_relu: bool =
 
 POOL_STATS = {"fused": 0}           # convolutions that pooled in their epilogue (tests)
 LAZY_STATS = {"handoffs": 0}        # GroupNorm backwards applied inside the first layer's correlation kernel (tests)
+
+
+def lazy_skip_ok(skip) -> bool:
+    """May the fused decoder operator hand the skip half's gradient to pool_fork's backward with GroupNorm's backward
+    pending?  (dense fp32 skip tensor with even D, H, W and whole channel quads)"""
+    return (torch.is_grad_enabled() and skip.shape[1] % 2 == 0 and skip.shape[2] % 2 == 0 and skip.shape[3] % 2 == 0
+            and skip.shape[4] % 4 == 0 and not os.environ.get("KEYMORPH_NO_LAZY_SKIP"))
 
 
 def lazy_first_layer_ok(x, cout1: int) -> bool:
@@ -790,6 +806,27 @@ class _PoolFork(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dskip):
+        lazy = getattr(dskip, "_kmh_lazy_gn", None) if dskip is not None else None
+        if lazy is not None and lazy[2] != dskip._version:
+            raise RuntimeError("keymorph_amd: the skip gradient's pending GroupNorm backward lost its tag (a hook modified "
+                               "the gradient?) -- set KEYMORPH_NO_LAZY_SKIP=1")
+        if lazy is not None:
+            lib = _lib.load()
+            c123, x, _ = lazy
+            N, D, H, W, C = ctx.xshape
+            dxn = _prep(dskip)
+            sc2 = torch.zeros(2, dtype=torch.float32, device=dxn.device) if _needs_range_scales() else None
+            if dy is None:                       # no pooled gradient: just the pending apply
+                check(lib.kmh_gn_bwd_apply(_p(dxn), _p(x), _p(c123), N, D * H * W, C, 1, 0, _p(dxn), _p(sc2), 0, _stream()),
+                      "kmh_gn_bwd_apply")
+                _tag_grad_scale(dxn, sc2)
+                return dxn
+            (arg,) = ctx.saved_tensors
+            dx = torch.empty((N, D, H, W, C), dtype=torch.float32, device=dxn.device)
+            check(lib.kmh_maxpool3d_bwd_lazy(_p(arg), _p(_prep(dy)), _p(dxn), _p(x), _p(c123), _p(dx), N, D, H, W, C, _p(sc2),
+                                             _stream()), "kmh_maxpool3d_bwd_lazy")
+            _tag_grad_scale(dx, sc2)
+            return dx
         if dy is None:
             return dskip
         return _maxpool_bwd(ctx, dy, dskip)

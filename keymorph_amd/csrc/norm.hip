@@ -425,6 +425,55 @@ __global__ __launch_bounds__(TPB) void maxpool_bwd4_kernel(const unsigned* __res
   }
 }
 
+// Pooling backward + skip gradient, with the skip gradient's GroupNorm backward still pending (round 3): the decoder's
+// fused upsample + concat + conv operator returns its normalised-input gradient dxn for the skip half untouched, and this
+// kernel forms  dx = scatter(dy) + [x > 0] (c1 dxn + c2 x + c3)  in one pass over the encoder output x -- the separate
+// kmh_gn_bwd_apply pass (read dxn, read x, write dskip) and this kernel's read of dskip are gone.  It also publishes
+// max |dx|, the next backward convolution's f16x3 range scale (exact, where the two-pass route carried a sum bound).
+__global__ __launch_bounds__(TPB) void maxpool_bwd4_lazy_kernel(const unsigned* __restrict__ argm, const float4* __restrict__ dy,
+                                                                const float4* __restrict__ dxn, const float4* __restrict__ x,
+                                                                const float* __restrict__ c123, float4* __restrict__ dx,
+                                                                int D, int H, int W, int C4, int Do, int Ho, int Wo,
+                                                                unsigned* __restrict__ amax) {
+  const int n = blockIdx.y;
+  const int total = Do * Ho * Wo * C4;
+  const long long V = (long long)D * H * W;
+  const float4* gn = dxn + (long long)n * V * C4;
+  const float4* xn = x + (long long)n * V * C4;
+  float4* dxo = dx + (long long)n * V * C4;
+  const float* cc = c123 + (long long)n * C4 * 12;
+  float mx = 0.f;
+  for (int e = blockIdx.x * TPB + threadIdx.x; e < total; e += gridDim.x * TPB) {
+    const int c = e % C4, v = e / C4;
+    const int xo = v % Wo, r = v / Wo, yo = r % Ho, zo = r / Ho;
+    const unsigned a = argm[(long long)n * total + e];
+    const float4 g = dy[(long long)n * total + e];
+    const int a0 = a & 255, a1 = (a >> 8) & 255, a2 = (a >> 16) & 255, a3 = a >> 24;
+    float k1[4], k2[4], k3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { k1[j] = cc[(4 * c + j) * 3]; k2[j] = cc[(4 * c + j) * 3 + 1]; k3[j] = cc[(4 * c + j) * 3 + 2]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int zz = 2 * zo + (k >> 2), yy = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+      const long long o = ((long long)(zz * H + yy) * W + xx) * C4 + c;
+      const float4 d4 = gn[o], x4 = xn[o];
+      const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+      float s4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {       // the same expression as gn_bwd_apply_kernel
+        float t = k1[j] * dd[j] + k2[j] * xv[j] + k3[j];
+        if (!(xv[j] > 0.f)) t = 0.f;
+        s4[j] = t;
+      }
+      float4 val = make_float4(k == a0 ? g.x : 0.f, k == a1 ? g.y : 0.f, k == a2 ? g.z : 0.f, k == a3 ? g.w : 0.f);
+      val.x += s4[0]; val.y += s4[1]; val.z += s4[2]; val.w += s4[3];
+      dxo[o] = val;
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(val.x), fabsf(val.y))), fmaxf(fabsf(val.z), fabsf(val.w)));
+    }
+  }
+  if (amax) kmh_absmax::publish(mx, amax);
+}
+
 // ---------------------------------------------------------------------------------------------
 // out[n, z,y,x, :] = cat(skip[n,z,y,x,:Cs], low[n, nearest(z,y,x), :Cl])
 __device__ __forceinline__ int nearest_src(int dst, int in_size, int out_size) {
@@ -776,6 +825,30 @@ KMH_API int kmh_maxpool3d_bwd(const float* x, const unsigned char* argmax, const
     maxpool_bwd_kernel<<<dim3(stream_blocks(pooled), N), TPB, 0, (hipStream_t)stream>>>(
         x, argmax, dy, add, add_cstride, dx, D, H, W, C, Do, Ho, Wo, out_blocked);
   }
+  return KMH_LAUNCH_CHECK();
+}
+
+/* dx = scatter(dy) + [x > 0] (c1 dxn + c2 x + c3): MaxPool3d(2)'s backward (winners from kmh_maxpool3d_fwd) summed with a
+ * second gradient of x whose GroupNorm backward (c123 (N,C,3), as kmh_gn_bwd_apply with relu_mask) is applied on the fly;
+ * x, dxn, dx (N,D,H,W,C) dense with even D, H, W and C % 4 == 0; dx_scale2 (2 floats) | NULL receives {S, 1/S} for max |dx|
+ * (autograd of max_pool3d + the skip connection of keymorph/unet3d/buildingblocks.py:363, 471-475). */
+KMH_API int kmh_maxpool3d_bwd_lazy(const unsigned char* argmax, const float* dy, const float* dxn, const float* x,
+                                   const float* c123, float* dx, int N, int D, int H, int W, int C, float* dx_scale2,
+                                   void* stream) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const long long pooled = (long long)Do * Ho * Wo * C;
+  if (!argmax || !dy || !dxn || !x || !c123 || !dx || (C & 3) || (D & 1) || (H & 1) || (W & 1)) return -22;
+  if (pooled / 4 >= (1ll << 31) || (long long)D * H * W >= (1ll << 31)) return -22;
+  if ((((uintptr_t)dxn | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dy) & 15) || ((uintptr_t)argmax & 3)) return -22;
+  hipStream_t s = (hipStream_t)stream;
+  if (dx_scale2) {
+    hipError_t e = hipMemsetAsync(dx_scale2, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  maxpool_bwd4_lazy_kernel<<<dim3(stream_blocks(pooled), N), TPB, 0, s>>>(
+      (const unsigned*)argmax, (const float4*)dy, (const float4*)dxn, (const float4*)x, c123, (float4*)dx, D, H, W, C / 4, Do,
+      Ho, Wo, reinterpret_cast<unsigned*>(dx_scale2));
+  if (dx_scale2) kmh_absmax::final_kernel<<<1, 1, 0, s>>>(dx_scale2, 0.f);
   return KMH_LAUNCH_CHECK();
 }
 

@@ -101,8 +101,11 @@ class Decoder(nn.Module):
         if B.upcat_conv_ok(encoder_features, x, c1.conv.out_channels):
             # interpolate + cat + the first SingleConv as one operator: no concatenated tensor, the upsampled channels
             # are convolved (forward) and differentiated (backward) at low resolution
+            # lazy_skip_grad: the skip tensor is pool_fork's second output, so its gradient goes to that node's backward
+            # only -- which then applies this operator's GroupNorm backward for the skip half itself (one pass less)
             h = B.upcat_conv_gcr(encoder_features, x, c1.groupnorm.weight, c1.groupnorm.bias, c1.conv.weight,
-                                 c1._groups, dy_premasked=True)     # its only consumer, SingleConv2, masks its dx
+                                 c1._groups, dy_premasked=True,     # its only consumer, SingleConv2, masks its dx
+                                 dskip_lazy=bool(lazy_skip_grad) and B.lazy_skip_ok(encoder_features))
             return dc.SingleConv2(h, out_premasked)
         return dc(B.upcat(encoder_features, x, lazy_skip_grad), out_premasked)
 
