@@ -9,6 +9,7 @@
 // register window (two x halves: 9 instead of 4.5 compute waves per 65 KB of LDS -- a 4-way split adds nothing):
 // per 4 voxels 2 x ds_read_b128 (the x row, and a TRANSPOSED dz row [co][x]) and 12 fp32 FMAs; S needs only the
 // row sum of dz and two end corrections.  Exact fp32, independent of the convolution arithmetic mode.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -181,6 +182,193 @@ __global__ __launch_bounds__(FL_TPB) void first_wgrad_kernel(const float* __rest
       o[(kz * 3 + ky) * 3 + kx] = R[kx];
       o[27 + (kz * 3 + ky) * 3 + kx] = S[kx];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: the same correlations on the fp32 MATRIX cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation --
+// the arithmetic class of the VALU kernel above, another summation order).  R is a GEMM after all, just a thin one:
+//   R[tap][co] = sum_v X[tap][v] dz[v][co],   X[tap][v] = x[v + tap]:  M = 27 taps (two 16-row tiles), N = 16, K = voxels.
+// The VALU kernel reads 32 bytes of LDS per 12 multiply-adds and runs at 0.22 of the VALU peak (LDS-read bound); here a wave
+// takes 4 consecutive voxels per step: A = 2 x ds_read_b32 (lane = (tap, voxel): a gather from the 3-plane input window),
+// B = one ds_read_b32 of the [x][co] gradient row, 2 MFMAs = 1728 multiply-adds.  Row 27 of the A operand is all ones: its
+// accumulator is the row sum of dz that the indicator correlations S need (reset after every row); S itself stays on the
+// VALU (144 threads x 3 adds per row).  With the GroupNorm backward of the next layer applied while the gradient row is
+// staged (c123), the kernel is bound by reading dxn and y once: 8.6 GB per step.
+constexpr int FM_TPB = 256;      // 4 waves: each takes every 4th group of 4 voxels of a row
+constexpr int FM_YR = 8;         // output rows per workgroup
+typedef float fm_f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                                 const float* __restrict__ dzmask,
+                                                                 float* __restrict__ partial /* (nblk, Cout, 2, 27) */,
+                                                                 int D, int H, int W, int Cout, int ytiles,
+                                                                 const float* __restrict__ c123) {
+  extern __shared__ __attribute__((aligned(16))) float fsm[];
+  const int WP = (W + 3) & ~3;
+  const int XP = WP + 8;                          // x row pitch: data at index 4.., zero halos either side
+  float* xs = fsm;                                // [3][FM_YR + 2][XP]
+  float* ds = fsm + 3 * (FM_YR + 2) * XP;         // [2][WP][16]   gradient row, [x][co]
+  float* srow = ds + 2 * WP * 16;                 // [2][4 waves][16]  per-wave row sums of dz (by row parity)
+  float* sfl = srow + 2 * 4 * 16;                 // [2][2][16]        first / last voxel of the row (by row parity)
+  float* sred = sfl + 2 * 2 * 16;                 // [4 waves][2 tiles][64 lanes][4]  final cross-wave reduction
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = blockIdx.z, z = blockIdx.y, y0 = blockIdx.x * FM_YR;
+  const float* xn = x + (long long)n * D * H * W;
+  const float* dn = dz + (long long)n * D * H * W * Cout;
+  const float* mn = dzmask ? dzmask + (long long)n * D * H * W * Cout : nullptr;
+  const bool v4 = ((W & 3) == 0) && ((Cout & 3) == 0);
+
+  // ---- input window: planes z-1..z+1, rows y0-1..y0+FM_YR, zero outside the volume (and in the x halos)
+  {
+    const int q_per_row = XP / 4;
+    for (int e = tid; e < 3 * (FM_YR + 2) * q_per_row; e += FM_TPB) {
+      const int qi = e % q_per_row, r = e / q_per_row;
+      const int ry = r % (FM_YR + 2), rz = r / (FM_YR + 2);
+      const int gx = 4 * qi - 4, gy = y0 + ry - 1, gz = z + rz - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D && gx >= 0 && gx < W) {
+        const float* src = xn + ((long long)gz * H + gy) * W + gx;
+        if (v4) v = *reinterpret_cast<const float4*>(src);
+        else {
+          v.x = src[0];
+          if (gx + 1 < W) v.y = src[1];
+          if (gx + 2 < W) v.z = src[2];
+          if (gx + 3 < W) v.w = src[3];
+        }
+      }
+      *reinterpret_cast<float4*>(xs + r * XP + 4 * qi) = v;
+    }
+  }
+  // ---- gradient row (z, y0 + yy) -> ds[buf][x][co]: global loads split from the LDS stores (the next row is in flight
+  // under this row's MFMAs); the pending GroupNorm backward and the ReLU mask are applied on the way
+  constexpr int NPRE = 4;                         // float4 items per thread: WP * 4 / FM_TPB <= 4 for W <= 256
+  float4 pre[NPRE];
+  float gc[4][3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * (tid & 3) + j;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gc[j][k] = (c123 && c < Cout) ? c123[((long long)n * Cout + c) * 3 + k] : 0.f;
+  }
+  auto load_dz = [&](int yy) {
+    const int gy = y0 + yy;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int e = tid + k * FM_TPB;
+      const int q = e & 3, xx = e >> 2;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < WP * 4 && xx < W && gy < H && 4 * q < Cout) {
+        const long long off = (((long long)z * H + gy) * W + xx) * Cout + 4 * q;
+        v = *reinterpret_cast<const float4*>(dn + off);
+        if (mn) {
+          const float4 m = *reinterpret_cast<const float4*>(mn + off);
+          if (c123) {            // the same expression as gn_bwd_apply_kernel
+            v.x = gc[0][0] * v.x + gc[0][1] * m.x + gc[0][2];
+            v.y = gc[1][0] * v.y + gc[1][1] * m.y + gc[1][2];
+            v.z = gc[2][0] * v.z + gc[2][1] * m.z + gc[2][2];
+            v.w = gc[3][0] * v.w + gc[3][1] * m.w + gc[3][2];
+          }
+          if (!(m.x > 0.f)) v.x = 0.f;
+          if (!(m.y > 0.f)) v.y = 0.f;
+          if (!(m.z > 0.f)) v.z = 0.f;
+          if (!(m.w > 0.f)) v.w = 0.f;
+        }
+      }
+      pre[k] = v;
+    }
+  };
+  auto store_dz = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int e = tid + k * FM_TPB;
+      if (e < WP * 4) *reinterpret_cast<float4*>(ds + (buf * WP + (e >> 2)) * 16 + 4 * (e & 3)) = pre[k];
+    }
+  };
+  auto stage_dz_scalar = [&](int yy, int buf) {
+    const int gy = y0 + yy;
+    for (int e = tid; e < WP * 16; e += FM_TPB) {
+      const int co = e & 15, xx = e >> 4;
+      float v = 0.f;
+      if (xx < W && gy < H && co < Cout) {
+        const long long off = (((long long)z * H + gy) * W + xx) * Cout + co;
+        v = dn[off];
+        if (mn && c123) {
+          const float* cc = c123 + ((long long)n * Cout + co) * 3;
+          v = cc[0] * v + cc[1] * mn[off] + cc[2];
+        }
+        if (mn && !(mn[off] > 0.f)) v = 0.f;
+      }
+      ds[(buf * WP + xx) * 16 + co] = v;
+    }
+  };
+  const bool pipelined = v4 && WP * 4 <= NPRE * FM_TPB;
+  if (pipelined) { load_dz(0); store_dz(0); } else stage_dz_scalar(0, 0);
+
+  // ---- MFMA operands of this lane: A row i = tap (two tiles), K index k = voxel within the group of 4
+  const int ai = lane & 15, ak = lane >> 4;
+  const int t0 = ai, t1 = 16 + ai;                       // taps of the two M tiles (t1 >= 27: padding; t1 == 27: the ones row)
+  const int offA0 = ((t0 / 9) * (FM_YR + 2) + (t0 / 3) % 3) * XP + 3 + t0 % 3 + ak;
+  const int offA1 = t1 < 27 ? ((t1 / 9) * (FM_YR + 2) + (t1 / 3) % 3) * XP + 3 + t1 % 3 + ak : -1;
+  const float a1_const = t1 == 27 ? 1.f : 0.f;
+  const int offB = ak * 16 + ai;
+  fm_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  // S: thread (co, (kz, ky)) as in the VALU kernel, fed by the row sums
+  const int sco = tid & 15, skzky = tid >> 4;
+  const int skz = skzky / 3, sky = skzky % 3;
+  float S[3] = {0.f, 0.f, 0.f};
+  auto s_update = [&](int yy) {                          // row yy's sums are complete (a barrier ago)
+    if (tid < 144 && y0 + yy < H) {
+      const float* sr = srow + (yy & 1) * 64;
+      const float rowsum = (sr[sco] + sr[16 + sco]) + (sr[32 + sco] + sr[48 + sco]);
+      const float first = sfl[(yy & 1) * 32 + sco], last = sfl[(yy & 1) * 32 + 16 + sco];
+      const int gy = y0 + yy + sky - 1, gz = z + skz - 1;
+      if ((unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D) {
+        S[1] += rowsum;
+        S[0] += rowsum - first;                          // kx = -1 leaves the volume at x = 0
+        S[2] += rowsum - last;                           // kx = +1 leaves it at x = W - 1
+      }
+    }
+  };
+  __syncthreads();
+  for (int yy = 0; yy < FM_YR; ++yy) {
+    if (yy + 1 < FM_YR) {
+      if (pipelined) load_dz(yy + 1); else stage_dz_scalar(yy + 1, (yy + 1) & 1);
+    }
+    if (yy > 0) s_update(yy - 1);
+    const float* xr = xs + yy * XP;
+    const float* dr = ds + (yy & 1) * WP * 16;
+    for (int x0 = 4 * wv; x0 < WP; x0 += 16) {
+      const float b = dr[x0 * 16 + offB];
+      const float a0 = xr[offA0 + x0];
+      const float a1 = offA1 >= 0 ? xr[offA1 + x0] : a1_const;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+    }
+    // the ones row (tile 1, row 11 = lanes 32..47, register 3) holds this wave's share of the row sums: hand it over, reset
+    if (ak == 2) { srow[(yy & 1) * 64 + wv * 16 + ai] = acc1[3]; acc1[3] = 0.f; }
+    if (tid < 16) { sfl[(yy & 1) * 32 + tid] = dr[tid]; sfl[(yy & 1) * 32 + 16 + tid] = dr[(W - 1) * 16 + tid]; }
+    if (pipelined && yy + 1 < FM_YR) store_dz((yy + 1) & 1);
+    __syncthreads();
+  }
+  s_update(FM_YR - 1);
+  // ---- R: sum the 4 waves' accumulators; element (tap, co) sits in lane (row / 4) * 16 + co, register row % 4
+  *reinterpret_cast<fm_f4*>(sred + ((wv * 2 + 0) * 64 + lane) * 4) = acc0;
+  *reinterpret_cast<fm_f4*>(sred + ((wv * 2 + 1) * 64 + lane) * 4) = acc1;
+  __syncthreads();
+  float* o = partial + ((((long long)n * gridDim.y + z) * ytiles + blockIdx.x)) * Cout * 54;
+  for (int e = tid; e < 27 * 16; e += FM_TPB) {
+    const int co = e & 15, t = e >> 4;
+    const int tile = t >> 4, row = t & 15;
+    const int l = (row >> 2) * 16 + co, r = row & 3;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += sred[((w * 2 + tile) * 64 + l) * 4 + r];
+    if (co < Cout) o[co * 54 + t] = v;
+  }
+  if (tid < 144 && sco < Cout) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) o[sco * 54 + 27 + (skz * 3 + sky) * 3 + kx] = S[kx];
   }
 }
 
@@ -389,8 +577,18 @@ KMH_API int kmh_conv3d_first_layer_wgrad(const float* x, const float* dz, const 
   hipError_t e = hipFuncSetAttribute((const void*)first_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int yt = ceil_div(H, FL_YR);
-  first_wgrad_kernel<<<dim3(yt, D, N), FL_TPB, lds, s>>>(x, dz, dzmask, (float*)ws, D, H, W, Cout, yt, c123);
   const int per = Cout * 54;
+  // matrix-core kernel (round 3) whenever its LDS image fits; KEYMORPH_FIRST_WGRAD_VALU=1 keeps the VALU kernel (A/B runs)
+  static const bool valu_only = getenv("KEYMORPH_FIRST_WGRAD_VALU") != nullptr;
+  const size_t lds_m = ((size_t)3 * (FM_YR + 2) * XP + (size_t)2 * WP * 16 + 2 * 4 * 16 + 2 * 2 * 16 + 4 * 2 * 64 * 4) * sizeof(float);
+  if (!valu_only && lds_m <= 160 * 1024 && FM_YR == FL_YR) {
+    hipError_t e2 = hipFuncSetAttribute((const void*)first_wgrad_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+    if (e2 != hipSuccess) return (int)e2;
+    first_wgrad_mfma_kernel<<<dim3(yt, D, N), FM_TPB, lds_m, s>>>(x, dz, dzmask, (float*)ws, D, H, W, Cout, yt, c123);
+    first_wgrad_reduce_kernel<<<dim3(ceil_div(per, 4), N), 256, 0, s>>>((const float*)ws, D * yt, per, rs);
+    return KMH_LAUNCH_CHECK();
+  }
+  first_wgrad_kernel<<<dim3(yt, D, N), FL_TPB, lds, s>>>(x, dz, dzmask, (float*)ws, D, H, W, Cout, yt, c123);
   first_wgrad_reduce_kernel<<<dim3(ceil_div(per, 4), N), 256, 0, s>>>((const float*)ws, D * yt * FL_XS, per, rs);
   return KMH_LAUNCH_CHECK();
 }

@@ -416,3 +416,33 @@ def test_conv_epilogue_pooling_tie_rule_and_whole_network(dispatch):
         assert float((va - vb).norm() / vb.norm()) < 1e-4
     finally:
         B.set_conv_mode(old)
+
+
+@pytest.mark.parametrize("cfg", [(2, (6, 11, 64), 16), (1, (5, 9, 100), 16), (2, (4, 17, 33), 12), (1, (9, 8, 256), 16),
+                                 (1, (3, 3, 7), 4)])
+def test_first_layer_correlation_kernel_vs_fp64(cfg):
+    """The first U-Net convolution (1 -> Cout <= 16): its weight / GroupNorm gradients come from the correlations of the
+    gradient with the raw image, computed on the fp32 matrix cores (first_wgrad_mfma_kernel, round 3) -- against fp64
+    autograd of GroupNorm(1, 1) -> Conv3d(1, Cout) -> ReLU on ragged rows (W = 100, 33, 7: scalar staging; 64, 256: the
+    pipelined 16-byte path), several samples, Cout 16 / 12 / 4, with a premasked cotangent."""
+    from keymorph_amd import backbone_ops as B
+    N, dims, Cout = cfg
+    D, H, W = dims
+    g = gen(600 + W)
+    img = torch.rand(N, D, H, W, 1, generator=g).to(DEV)
+    gamma, beta = torch.tensor([1.3], device=DEV), torch.tensor([-0.2], device=DEV)
+    w = (torch.randn(Cout, 1, 3, 3, 3, generator=g) / np.sqrt(27.0)).to(DEV)
+    cot = torch.randn(N, D, H, W, Cout, generator=g).to(DEV)
+    Hh = [t.clone().requires_grad_(True) for t in (gamma, beta, w)]
+    yh = B.single_conv_gcr(img, Hh[0], Hh[1], Hh[2], 1, x_from_relu=False, dy_premasked=True)
+    cotm = cot * (yh.detach() > 0)
+    (yh * cotm).sum().backward()
+    R = [t.double().clone().requires_grad_(True) for t in (gamma, beta, w)]
+    pre = conv3_fp64(group_norm_fp64(img.double(), 1, R[0], R[1]), R[2])
+    (pre * cotm.double()).sum().backward()
+    assert rel(yh, torch.relu(pre.detach())) < 3e-6
+    assert rel(Hh[2].grad, R[2].grad) < 3e-6, rel(Hh[2].grad, R[2].grad)
+    # the one-element GroupNorm parameters: sums over the whole volume, compared against the size of their terms
+    scale = float((cotm.double().abs() * pre.detach().abs()).sum()) + 1e-30
+    assert abs(float(Hh[0].grad) - float(R[0].grad)) < 1e-6 * scale
+    assert abs(float(Hh[1].grad) - float(R[1].grad)) < 1e-6 * scale
