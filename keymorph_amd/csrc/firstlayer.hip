@@ -211,7 +211,7 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
   float* ds = fsm + 3 * (FM_YR + 2) * XP;         // [2][WP][16]   gradient row, [x][co]
   float* srow = ds + 2 * WP * 16;                 // [2][4 waves][16]  per-wave row sums of dz (by row parity)
   float* sfl = srow + 2 * 4 * 16;                 // [2][2][16]        first / last voxel of the row (by row parity)
-  float* sred = sfl + 2 * 2 * 16;                 // [4 waves][2 tiles][64 lanes][4]  final cross-wave reduction
+  float* sred = sfl + 2 * 2 * 16;                 // [4 waves][2 tiles][64 lanes][4] DOUBLES: final cross-wave reduction
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = blockIdx.z, z = blockIdx.y, y0 = blockIdx.x * FM_YR;
   const float* xn = x + (long long)n * D * H * W;
@@ -313,15 +313,16 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
   const float a1_const = t1 == 27 ? 1.f : 0.f;
   const int offB = ak * 16 + ai;
   fm_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  double racc0[4] = {0.0, 0.0, 0.0, 0.0}, racc1[4] = {0.0, 0.0, 0.0, 0.0};
   // S: thread (co, (kz, ky)) as in the VALU kernel, fed by the row sums
   const int sco = tid & 15, skzky = tid >> 4;
   const int skz = skzky / 3, sky = skzky % 3;
-  float S[3] = {0.f, 0.f, 0.f};
+  double S[3] = {0.0, 0.0, 0.0};
   auto s_update = [&](int yy) {                          // row yy's sums are complete (a barrier ago)
     if (tid < 144 && y0 + yy < H) {
       const float* sr = srow + (yy & 1) * 64;
-      const float rowsum = (sr[sco] + sr[16 + sco]) + (sr[32 + sco] + sr[48 + sco]);
-      const float first = sfl[(yy & 1) * 32 + sco], last = sfl[(yy & 1) * 32 + 16 + sco];
+      const double rowsum = ((double)sr[sco] + (double)sr[16 + sco]) + ((double)sr[32 + sco] + (double)sr[48 + sco]);
+      const double first = sfl[(yy & 1) * 32 + sco], last = sfl[(yy & 1) * 32 + 16 + sco];
       const int gy = y0 + yy + sky - 1, gz = z + skz - 1;
       if ((unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D) {
         S[1] += rowsum;
@@ -345,30 +346,38 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
     }
-    // the ones row (tile 1, row 11 = lanes 32..47, register 3) holds this wave's share of the row sums: hand it over, reset
-    if (ak == 2) { srow[(yy & 1) * 64 + wv * 16 + ai] = acc1[3]; acc1[3] = 0.f; }
+    // the ones row (tile 1, row 11 = lanes 32..47, register 3) holds this wave's share of the row sums: hand it over
+    if (ak == 2) srow[(yy & 1) * 64 + wv * 16 + ai] = acc1[3];
+    // fp32 accumulation chains end with the row (64 voxels per wave): the row's sums go into fp64 accumulators
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { racc0[r] += (double)acc0[r]; racc1[r] += (double)acc1[r]; acc0[r] = 0.f; acc1[r] = 0.f; }
     if (tid < 16) { sfl[(yy & 1) * 32 + tid] = dr[tid]; sfl[(yy & 1) * 32 + 16 + tid] = dr[(W - 1) * 16 + tid]; }
     if (pipelined && yy + 1 < FM_YR) store_dz((yy + 1) & 1);
     __syncthreads();
   }
   s_update(FM_YR - 1);
   // ---- R: sum the 4 waves' accumulators; element (tap, co) sits in lane (row / 4) * 16 + co, register row % 4
-  *reinterpret_cast<fm_f4*>(sred + ((wv * 2 + 0) * 64 + lane) * 4) = acc0;
-  *reinterpret_cast<fm_f4*>(sred + ((wv * 2 + 1) * 64 + lane) * 4) = acc1;
+  // (the cross-wave sum is formed in fp64 as well: sred holds doubles)
+  double* dred = reinterpret_cast<double*>(sred);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    dred[((wv * 2 + 0) * 64 + lane) * 4 + r] = racc0[r];
+    dred[((wv * 2 + 1) * 64 + lane) * 4 + r] = racc1[r];
+  }
   __syncthreads();
   float* o = partial + ((((long long)n * gridDim.y + z) * ytiles + blockIdx.x)) * Cout * 54;
   for (int e = tid; e < 27 * 16; e += FM_TPB) {
     const int co = e & 15, t = e >> 4;
     const int tile = t >> 4, row = t & 15;
     const int l = (row >> 2) * 16 + co, r = row & 3;
-    float v = 0.f;
+    double v = 0.0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += sred[((w * 2 + tile) * 64 + l) * 4 + r];
-    if (co < Cout) o[co * 54 + t] = v;
+    for (int w = 0; w < 4; ++w) v += dred[((w * 2 + tile) * 64 + l) * 4 + r];
+    if (co < Cout) o[co * 54 + t] = (float)v;
   }
   if (tid < 144 && sco < Cout) {
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) o[sco * 54 + 27 + (skz * 3 + sky) * 3 + kx] = S[kx];
+    for (int kx = 0; kx < 3; ++kx) o[sco * 54 + 27 + (skz * 3 + sky) * 3 + kx] = (float)S[kx];
   }
 }
 
@@ -580,7 +589,7 @@ KMH_API int kmh_conv3d_first_layer_wgrad(const float* x, const float* dz, const 
   const int per = Cout * 54;
   // matrix-core kernel (round 3) whenever its LDS image fits; KEYMORPH_FIRST_WGRAD_VALU=1 keeps the VALU kernel (A/B runs)
   static const bool valu_only = getenv("KEYMORPH_FIRST_WGRAD_VALU") != nullptr;
-  const size_t lds_m = ((size_t)3 * (FM_YR + 2) * XP + (size_t)2 * WP * 16 + 2 * 4 * 16 + 2 * 2 * 16 + 4 * 2 * 64 * 4) * sizeof(float);
+  const size_t lds_m = ((size_t)3 * (FM_YR + 2) * XP + (size_t)2 * WP * 16 + 2 * 4 * 16 + 2 * 2 * 16 + 2 * 4 * 2 * 64 * 4) * sizeof(float);
   if (!valu_only && lds_m <= 160 * 1024 && FM_YR == FL_YR) {
     hipError_t e2 = hipFuncSetAttribute((const void*)first_wgrad_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
     if (e2 != hipSuccess) return (int)e2;

@@ -276,6 +276,7 @@ def test_groupwise_8x256(world, tmp_path):
         solo = torch.cat([km.get_keypoints(stack[i:i + 1]) for i in (0, 3, 7)])
     pts = res["affine"]["grouppoints_m"]
     assert pts.shape == (n_sub, K, 3)
+    print(f"groupwise 8x256: stack keypoints vs solo {float((pts[[0, 3, 7]] - solo).abs().max()):.2e}")
     close(pts[[0, 3, 7]], solo, 2e-6)                 # the stack's keypoints are each subject's own
     g = torch.Generator().manual_seed(5)
     idx = tuple(torch.randint(0, SIZE, (4096,), generator=g) for _ in range(3))
@@ -287,12 +288,15 @@ def test_groupwise_8x256(world, tmp_path):
         # the iterations against the oracle's (fp32 CPU) on OUR keypoints: model.py:331-444
         if tt != "tps_0":       # lambda = 0 on the clumped keypoints of a random-init net: conditioning, not arithmetic
             pa, mean = O.groupwise_points(pts.cpu(), tt, iters)
+            print(f"groupwise 8x256 {tt}: aligned points vs oracle {float((r['grouppoints_a'].cpu() - pa).abs().max()):.2e}")
             close(r["grouppoints_a"], pa, 1e-4)
             for i in (0, 5):
                 grid = np.load(os.path.join(tmp_path, files[i]), mmap_mode="r")
                 assert grid.shape == (1, SIZE, SIZE, SIZE, 3) and grid.dtype == np.float32
                 ours = torch.from_numpy(np.ascontiguousarray(grid[0][idx[0].numpy(), idx[1].numpy(), idx[2].numpy()]))
-                close(ours, _oracle_grid_samples(pts[i:i + 1].cpu(), mean, tt, idx), 1e-4)
+                want = _oracle_grid_samples(pts[i:i + 1].cpu(), mean, tt, idx)
+                print(f"groupwise 8x256 {tt} subject {i}: grid samples vs oracle {float((ours - want).abs().max()):.2e}")
+                close(ours, want, 1e-4)
         else:
             grid = np.load(os.path.join(tmp_path, files[2]), mmap_mode="r")
             assert grid.shape == (1, SIZE, SIZE, SIZE, 3) and bool(np.isfinite(grid[0, ::8, ::8, ::8]).all())
