@@ -237,16 +237,16 @@ size_t kmh_conv3d_first_layer_fwd_ws_bytes(int N, int D, int H, int W, int Cout)
 int kmh_conv3d_first_layer_fwd(const float* x, const float* scale, const float* shift, const float* w, float* y, int N,
                                int D, int H, int W, int Cout, void* ws, double* stats_out, void* stream);
 /* first U-Net layer (Cin = 1), backward of keymorph/unet3d/buildingblocks.py:46-78 for encoders[0] without the
- * 1-channel data gradient: rs (N,Cout,2,27) = correlations of dz with the RAW input (R) and with the indicator of the
+ * 1-channel data gradient: rs (N,Cout,2,27) (doubles; rs_f64 = 1 in the fold) = correlations of dz with the RAW input (R) and with the indicator of the
  * volume (S), by a dedicated exact-fp32 kernel (Cout <= 16); then ... */
 size_t kmh_conv3d_first_layer_wgrad_ws_bytes(int N, int D, int H, int W, int Cout);
 /* c123 (N,Cout,3) | NULL (needs dzmask): the gradient entering the correlations is [dzmask > 0] (c1 dz + c2 dzmask + c3)
  * -- the NEXT layer's GroupNorm backward (what kmh_gn_bwd_apply would have written) applied while dz is staged */
-int kmh_conv3d_first_layer_wgrad(const float* x, const float* dz, const float* dzmask, const float* c123, float* rs, int N,
+int kmh_conv3d_first_layer_wgrad(const float* x, const float* dz, const float* dzmask, const float* c123, double* rs, int N,
                                  int D, int H, int W, int Cout, void* ws, void* stream);
 /* ... fold the (x, 1) correlations of one sample into dw and GroupNorm's (A, B) sums */
-int kmh_conv3d_first_layer_fold(const float* rs, const float* w, const float* scale_n, const float* shift_n,
-                                int Cout, float* dw, double* ab_n, int accumulate, void* stream);
+int kmh_conv3d_first_layer_fold(const void* rs, int rs_f64, const float* w, const float* scale_n, const float* shift_n, int Cout,
+                                float* dw, double* ab_n, int accumulate, void* stream);
 /* dw (Cout,Cin,3,3,3) (+)= sum_v act_in(x*scale+shift)[v+tap] dz[v]*[dzmask[v] > 0]  (dzmask may be NULL) */
 size_t kmh_conv3d_wgrad_ws_bytes(int N, int D, int H, int W, int Cin, int Cout);
 int kmh_conv3d_wgrad(const float* x, const float* scale, const float* shift, const float* dz,

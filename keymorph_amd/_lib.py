@@ -82,7 +82,7 @@ PROTOS = {
     "kmh_conv3d_wgrad_bf_blocked_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "kmh_conv3d_first_layer_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "kmh_conv3d_first_layer_wgrad": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f]),
-    "kmh_conv3d_first_layer_fold": (_i, [_f, _f, _f, _f, _i, _f, _f, _i, _f]),
+    "kmh_conv3d_first_layer_fold": (_i, [_f, _i, _f, _f, _f, _i, _f, _f, _i, _f]),
     "kmh_conv3d_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "kmh_conv3d_wgrad": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f]),
     "kmh_channel_stats_ws_bytes": (_sz, [_i, _i]),

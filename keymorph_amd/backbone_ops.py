@@ -265,7 +265,7 @@ def first_layer_grads(x, scale, shift, mr, gamma, weight, dy, ymask, N, D, H, W,
     dw = _f32((Cout, 1, 3, 3, 3), x.device)
     ab = torch.empty((N, 1, 2), dtype=torch.float64, device=x.device)
     if Cout <= 16:
-        rs = _f32((N, Cout, 2, 27), x.device)
+        rs = torch.empty((N, Cout, 2, 27), dtype=torch.float64, device=x.device)      # kept in fp64 until folded
         ws = workspace(int(lib.kmh_conv3d_first_layer_wgrad_ws_bytes(N, D, H, W, Cout)), x.device, "wgrad")
         if _lib.profiler.enabled:
             _lib.profiler.meta = {"flops": 2.0 * 27 * 2 * Cout * V * N, "shape": (N, D, H, W, 1, Cout)}
@@ -274,7 +274,7 @@ def first_layer_grads(x, scale, shift, mr, gamma, weight, dy, ymask, N, D, H, W,
         check(lib.kmh_conv3d_first_layer_wgrad(_p(x), _p(dy), _p(ymask), _p(lazy_c123), _p(rs), N, D, H, W, Cout, _p(ws),
                                                _stream()), "kmh_conv3d_first_layer_wgrad")
         for n in range(N):
-            check(lib.kmh_conv3d_first_layer_fold(_p(rs[n]), _p(weight), _p(scale[n]), _p(shift[n]), Cout, _p(dw),
+            check(lib.kmh_conv3d_first_layer_fold(_p(rs[n]), 1, _p(weight), _p(scale[n]), _p(shift[n]), Cout, _p(dw),
                                                   _p(ab[n]), int(n > 0), _stream()), "kmh_conv3d_first_layer_fold")
     else:
         assert lazy_c123 is None
@@ -290,7 +290,7 @@ def first_layer_grads(x, scale, shift, mr, gamma, weight, dy, ymask, N, D, H, W,
             check(lib.kmh_conv3d_wgrad_bf(_p(x[n]), None, None, _p(dy[n]), _p(None if ymask is None else ymask[n]),
                                           _p(rs), 1, D, H, W, 2, Cout, 0, 0, terms, 1, _p(xscale), _p(dscale), 0, None, None,
                                           _p(ws), _stream()), "kmh_conv3d_wgrad_bf")
-            check(lib.kmh_conv3d_first_layer_fold(_p(rs), _p(weight), _p(scale[n]), _p(shift[n]), Cout, _p(dw),
+            check(lib.kmh_conv3d_first_layer_fold(_p(rs), 0, _p(weight), _p(scale[n]), _p(shift[n]), Cout, _p(dw),
                                                   _p(ab[n]), int(n > 0), _stream()), "kmh_conv3d_first_layer_fold")
     c123 = _f32((N, 1, 3), x.device)
     dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)

@@ -2565,7 +2565,8 @@ KMH_API int kmh_conv3d_wgrad_bf(const float* x, const float* scale, const float*
 // produce  dw (+)= scale*R + shift*S   (the gradient wrt the filter applied to the NORMALISED input) and
 //          ab = (A, B) = (sum dxn, sum dxn*x) = (sum_{co,tap} W S, sum_{co,tap} W R)  without ever forming dxn.
 namespace {
-__global__ __launch_bounds__(256) void first_layer_fold_kernel(const float* __restrict__ rs, const float* __restrict__ w,
+template <typename RS>
+__global__ __launch_bounds__(256) void first_layer_fold_kernel(const RS* __restrict__ rs, const float* __restrict__ w,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift, int Cout,
                                                                float* __restrict__ dw, double* __restrict__ ab,
@@ -2574,8 +2575,8 @@ __global__ __launch_bounds__(256) void first_layer_fold_kernel(const float* __re
   double a = 0, b = 0;
   for (int e = threadIdx.x; e < Cout * 27; e += 256) {
     const int co = e / 27, tap = e % 27;
-    const float R = rs[(co * 2 + 0) * 27 + tap], S = rs[(co * 2 + 1) * 27 + tap];
-    const float g = sc * R + sh * S;
+    const RS R = rs[(co * 2 + 0) * 27 + tap], S = rs[(co * 2 + 1) * 27 + tap];      // (fp64 from the dedicated kernel)
+    const float g = (float)((RS)sc * R + (RS)sh * S);
     dw[e] = accumulate ? dw[e] + g : g;
     a += (double)w[e] * (double)S;
     b += (double)w[e] * (double)R;
@@ -2587,8 +2588,14 @@ __global__ __launch_bounds__(256) void first_layer_fold_kernel(const float* __re
 }
 }  // namespace
 
-KMH_API int kmh_conv3d_first_layer_fold(const float* rs, const float* w, const float* scale_n, const float* shift_n,
+/* rs_f64 != 0: rs holds doubles (what kmh_conv3d_first_layer_wgrad writes: GroupNorm's sums over the whole volume cancel to
+ * ~1e-3 of their terms, so the correlations are kept in fp64 until they are folded); 0: floats (the split-operand weight
+ * gradient over the virtual 2-channel input, Cout > 16) */
+KMH_API int kmh_conv3d_first_layer_fold(const void* rs, int rs_f64, const float* w, const float* scale_n, const float* shift_n,
                                         int Cout, float* dw, double* ab_n, int accumulate, void* stream) {
-  first_layer_fold_kernel<<<1, 256, 0, (hipStream_t)stream>>>(rs, w, scale_n, shift_n, Cout, dw, ab_n, accumulate);
+  if (rs_f64)
+    first_layer_fold_kernel<double><<<1, 256, 0, (hipStream_t)stream>>>((const double*)rs, w, scale_n, shift_n, Cout, dw, ab_n, accumulate);
+  else
+    first_layer_fold_kernel<float><<<1, 256, 0, (hipStream_t)stream>>>((const float*)rs, w, scale_n, shift_n, Cout, dw, ab_n, accumulate);
   return KMH_LAUNCH_CHECK();
 }

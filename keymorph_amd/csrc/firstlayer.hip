@@ -383,7 +383,7 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
 
 // rs[n][e] = sum over the sample's workgroups, fixed order in fp64
 __global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int per,
-                                                                float* __restrict__ rs) {
+                                                                double* __restrict__ rs) {
   const int n = blockIdx.y;
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= per) return;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __
   }
   for (; b < nblk; b += 64) s4[0] += p[(long long)b * per];
   const double s = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
-  if (lane == 0) rs[(long long)n * per + e] = (float)s;
+  if (lane == 0) rs[(long long)n * per + e] = s;
 }
 
 
@@ -573,10 +573,10 @@ KMH_API size_t kmh_conv3d_first_layer_wgrad_ws_bytes(int N, int D, int H, int W,
 }
 
 /* x (N,D,H,W) raw 1-channel input, dz (N,D,H,W,Cout) with Cout <= 16, dzmask like dz or NULL ->
- * rs (N,Cout,2,27): rs[n][co][0][tap] = R, rs[n][co][1][tap] = S  (the input of kmh_conv3d_first_layer_fold).
+ * rs (N,Cout,2,27) DOUBLES: rs[n][co][0][tap] = R, rs[n][co][1][tap] = S  (the input of kmh_conv3d_first_layer_fold).
  * c123 (N,Cout,3) | NULL (needs dzmask): the gradient is [dzmask > 0] (c1 dz + c2 dzmask + c3), i.e. the NEXT layer's
  * GroupNorm backward (kmh_gn_bwd_apply with relu_mask) applied on the fly to its normalised-input gradient dz. */
-KMH_API int kmh_conv3d_first_layer_wgrad(const float* x, const float* dz, const float* dzmask, const float* c123, float* rs,
+KMH_API int kmh_conv3d_first_layer_wgrad(const float* x, const float* dz, const float* dzmask, const float* c123, double* rs,
                                          int N, int D, int H, int W, int Cout, void* ws, void* stream) {
   if (Cout > FL_CO || Cout < 1 || W < 1 || (c123 && !dzmask)) return -22;
   hipStream_t s = (hipStream_t)stream;
