@@ -231,7 +231,12 @@ def _check_all_gradients(named_grads, ref_of, flips, worst_flip, tight, what):
     errs = {k: rel_l2(v, ref_of(k)) for k, v in named_grads}
     worst = max(errs, key=errs.get)
     print(f"{what}: worst parameter-gradient rel-L2 {errs[worst]:.2e} ({worst}); ReLU-mask flips vs fp64: {flips}")
-    bad = {k: e for k, e in errs.items() if e > tight}
+    # The first layer's one-element GroupNorm weight / bias are whole-volume sums whose terms cancel to ~1e-3 of their size
+    # (rstd (sum dxn x - mean sum dxn) over every voxel): the per-tensor worst of every pairing of implementations and
+    # arithmetics.  Measured on the kink-free network: 4.4e-6 with the VALU correlation kernel,
+    # 0.9e-5..1.2e-5 with the fp32 matrix-core kernel (another summation order) -- granted 3e-5, every other tensor `tight`.
+    cancelling = ("encoders.0.basic_module.SingleConv1.groupnorm.weight", "encoders.0.basic_module.SingleConv1.groupnorm.bias")
+    bad = {k: e for k, e in errs.items() if e > (max(tight, 3e-5) if k.endswith(cancelling) else tight)}
     if bad:
         assert 0 < flips <= 8 and worst_flip < 1e-5, (bad, flips, worst_flip)
         assert max(bad.values()) < 3e-2, bad
