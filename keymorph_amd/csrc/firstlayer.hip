@@ -209,9 +209,10 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
   const int XP = WP + 8;                          // x row pitch: data at index 4.., zero halos either side
   float* xs = fsm;                                // [3][FM_YR + 2][XP]
   float* ds = fsm + 3 * (FM_YR + 2) * XP;         // [2][WP][16]   gradient row, [x][co]
-  float* srow = ds + 2 * WP * 16;                 // [2][4 waves][16]  per-wave row sums of dz (by row parity)
+  float* srow = ds + (2 * WP * 16 > 4096 ? 2 * WP * 16 : 4096);   // [2][4 waves][16]  per-wave row sums of dz (by row parity)
   float* sfl = srow + 2 * 4 * 16;                 // [2][2][16]        first / last voxel of the row (by row parity)
-  float* sred = sfl + 2 * 2 * 16;                 // [4 waves][2 tiles][64 lanes][4] DOUBLES: final cross-wave reduction
+  // (the final cross-wave reduction, [4 waves][2 tiles][64 lanes][4] doubles = 16 KB, re-uses the gradient-row buffers: with
+  // its own 16 KB the image was 81.6 KB and only ONE workgroup fitted a CU -- 32 KB of loads in flight per CU)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = blockIdx.z, z = blockIdx.y, y0 = blockIdx.x * FM_YR;
   const float* xn = x + (long long)n * D * H * W;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
   // ---- gradient row (z, y0 + yy) -> ds[buf][x][co]: global loads split from the LDS stores (the next row is in flight
   // under this row's MFMAs); the pending GroupNorm backward and the ReLU mask are applied on the way
   constexpr int NPRE = 4;                         // float4 items per thread: WP * 4 / FM_TPB <= 4 for W <= 256
-  float4 pre[NPRE];
+  float4 preA[NPRE], preB[NPRE];                  // two rows in flight: row yy + 1 and row yy + 2
   float gc[4][3];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < 3; ++k) gc[j][k] = (c123 && c < Cout) ? c123[((long long)n * Cout + c) * 3 + k] : 0.f;
   }
-  auto load_dz = [&](int yy) {
+  auto load_dz = [&](int yy, float4 (&pre)[NPRE]) {
     const int gy = y0 + yy;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
       pre[k] = v;
     }
   };
-  auto store_dz = [&](int buf) {
+  auto store_dz = [&](int buf, const float4 (&pre)[NPRE]) {
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
       const int e = tid + k * FM_TPB;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
     }
   };
   const bool pipelined = v4 && WP * 4 <= NPRE * FM_TPB;
-  if (pipelined) { load_dz(0); store_dz(0); } else stage_dz_scalar(0, 0);
+  if (pipelined) { load_dz(0, preA); store_dz(0, preA); load_dz(1, preB); } else stage_dz_scalar(0, 0);
 
   // ---- MFMA operands of this lane: A row i = tap (two tiles), K index k = voxel within the group of 4
   const int ai = lane & 15, ak = lane >> 4;
@@ -332,10 +333,13 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
     }
   };
   __syncthreads();
+  static_assert(FM_YR % 2 == 0, "the row loop is unrolled by two (register double-buffer of the prefetched rows)");
+#pragma unroll
   for (int yy = 0; yy < FM_YR; ++yy) {
-    if (yy + 1 < FM_YR) {
-      if (pipelined) load_dz(yy + 1); else stage_dz_scalar(yy + 1, (yy + 1) & 1);
-    }
+    // rows yy + 1 (issued an iteration ago) and yy + 2 (issued now) are in flight under this row's MFMAs
+    if (pipelined) {
+      if (yy + 2 < FM_YR) { if (yy & 1) load_dz(yy + 2, preB); else load_dz(yy + 2, preA); }
+    } else if (yy + 1 < FM_YR) stage_dz_scalar(yy + 1, (yy + 1) & 1);
     if (yy > 0) s_update(yy - 1);
     const float* xr = xs + yy * XP;
     const float* dr = ds + (yy & 1) * WP * 16;
@@ -352,13 +356,13 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
 #pragma unroll
     for (int r = 0; r < 4; ++r) { racc0[r] += (double)acc0[r]; racc1[r] += (double)acc1[r]; acc0[r] = 0.f; acc1[r] = 0.f; }
     if (tid < 16) { sfl[(yy & 1) * 32 + tid] = dr[tid]; sfl[(yy & 1) * 32 + 16 + tid] = dr[(W - 1) * 16 + tid]; }
-    if (pipelined && yy + 1 < FM_YR) store_dz((yy + 1) & 1);
+    if (pipelined && yy + 1 < FM_YR) { if (yy & 1) store_dz((yy + 1) & 1, preA); else store_dz((yy + 1) & 1, preB); }
     __syncthreads();
   }
   s_update(FM_YR - 1);
   // ---- R: sum the 4 waves' accumulators; element (tap, co) sits in lane (row / 4) * 16 + co, register row % 4
-  // (the cross-wave sum is formed in fp64 as well: sred holds doubles)
-  double* dred = reinterpret_cast<double*>(sred);
+  // (the cross-wave sum is formed in fp64 as well; every wave is past the last row's barrier: ds is free)
+  double* dred = reinterpret_cast<double*>(ds);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     dred[((wv * 2 + 0) * 64 + lane) * 4 + r] = racc0[r];
@@ -589,7 +593,9 @@ KMH_API int kmh_conv3d_first_layer_wgrad(const float* x, const float* dz, const 
   const int per = Cout * 54;
   // matrix-core kernel (round 3) whenever its LDS image fits; KEYMORPH_FIRST_WGRAD_VALU=1 keeps the VALU kernel (A/B runs)
   static const bool valu_only = getenv("KEYMORPH_FIRST_WGRAD_VALU") != nullptr;
-  const size_t lds_m = ((size_t)3 * (FM_YR + 2) * XP + (size_t)2 * WP * 16 + 2 * 4 * 16 + 2 * 2 * 16 + 2 * 4 * 2 * 64 * 4) * sizeof(float);
+  size_t ds_floats = (size_t)2 * WP * 16;
+  if (ds_floats < 2 * 4 * 2 * 64 * 4) ds_floats = 2 * 4 * 2 * 64 * 4;          // room for the final reduction (16 KB of doubles)
+  const size_t lds_m = ((size_t)3 * (FM_YR + 2) * XP + ds_floats + 2 * 4 * 16 + 2 * 2 * 16) * sizeof(float);
   if (!valu_only && lds_m <= 160 * 1024 && FM_YR == FL_YR) {
     hipError_t e2 = hipFuncSetAttribute((const void*)first_wgrad_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
     if (e2 != hipSuccess) return (int)e2;
