@@ -899,3 +899,28 @@ def test_skip_gradient_lazy_groupnorm_backward_in_pool_fork(monkeypatch):
             assert float((a - r).norm() / (r.norm() + 1e-30)) < bar, k
     finally:
         B.set_conv_mode(old)
+
+
+def test_pool_fork_backward_with_a_misaligned_skip_gradient_view():
+    """kmh_maxpool3d_bwd's 16-byte kernel reads the second gradient as float4: a channel-slice view whose storage offset is
+    not a multiple of 4 floats must take the scalar kernel (round-2 advisor finding) -- same result either way"""
+    from keymorph_amd import backbone_ops as B, _lib
+    from keymorph_amd.ops import _p, _stream
+    lib = _lib.load()
+    g = gen(51)
+    N, D, H, W, C = 1, 4, 6, 8, 8
+    x = torch.randn(N, D, H, W, C, generator=g).to(DEV)
+    y = torch.empty(N, D // 2, H // 2, W // 2, C, device=DEV)
+    arg = torch.empty(y.shape, dtype=torch.uint8, device=DEV)
+    assert lib.kmh_maxpool3d_fwd(_p(x), _p(y), _p(arg), N, D, H, W, C, _stream()) == 0
+    dy = torch.randn(y.shape, generator=g).to(DEV)
+    wide = torch.randn(N, D, H, W, C + 4, generator=g).to(DEV)        # the skip gradient lives at channel offset 1: misaligned
+    add = wide[..., 1:1 + C]
+    assert add.data_ptr() % 16 != 0 and add.stride(3) == C + 4
+    dx = torch.empty_like(x)
+    assert lib.kmh_maxpool3d_bwd(None, _p(arg), _p(dy), _p(add), C + 4, _p(dx), N, D, H, W, C, 0, _stream()) == 0
+    dx2 = torch.empty_like(x)
+    addc = add.contiguous()
+    assert lib.kmh_maxpool3d_bwd(None, _p(arg), _p(dy), _p(addc), C, _p(dx2), N, D, H, W, C, 0, _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx2)

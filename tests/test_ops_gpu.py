@@ -466,3 +466,41 @@ def test_jacobian_metrics_golden_and_oracle():
     close(got, ref, 1e-5, 1e-5)
     assert abs(L.jdstd(disp.to(DEV)) - float(ref.double().std(unbiased=False))) < 1e-5
     assert abs(L.jdlessthan0(disp.to(DEV)) - int((ref <= 0).sum())) <= 2            # ties at exactly 0 in fp32
+
+
+# ---------------------------------------------------------------- round-2 advisor findings, pinned
+def test_warp_mse_backward_twice_over_a_retained_graph():
+    """the fused warp + MSE pass writes d(loss)/d(grid) in the forward; a second backward over the same graph
+    (retain_graph) used to crash on empty saved tensors -- it now recomputes through the plain three-launch route"""
+    g = gen(41)
+    x = torch.rand(1, 1, 9, 10, 12, generator=g).to(DEV)
+    f = torch.rand(1, 1, 9, 10, 12, generator=g).to(DEV)
+    grid = (torch.rand(1, 9, 10, 12, 3, generator=g) * 2.2 - 1.1).to(DEV).requires_grad_(True)
+    loss, _ = ops().warp_mse(x, grid, f)
+    (g1,) = torch.autograd.grad(loss, grid, retain_graph=True)
+    g1 = g1.clone()
+    (g2,) = torch.autograd.grad(loss, grid, grad_outputs=torch.tensor(2.0, device=DEV), retain_graph=True)
+    (g3,) = torch.autograd.grad(loss, grid)
+    gr = grid.detach().cpu().requires_grad_(True)
+    O.mse_loss(f.cpu(), O.align_img(gr, x.cpu())).backward()
+    close(g1, gr.grad, 1e-7, 1e-4)
+    close(g2, 2 * gr.grad, 2e-7, 1e-4)
+    close(g3, gr.grad, 1e-7, 1e-4)
+
+
+def test_one_hot_many_labels_empty_intersection_and_wrong_device():
+    """utils.one_hot / one_hot_subsampled_pair at the edges (keymorph/utils.py:200-240): more than 256 channels (FreeSurfer
+    aparc+aseg ids reach 2035) is encoded in slices; label maps without a shared label give the reference's (N, 0, ...)
+    tensors instead of an error"""
+    from keymorph_amd import utils
+    g = gen(42)
+    seg = torch.randint(0, 700, (2, 1, 5, 6, 7), generator=g)
+    seg[0, 0, 0, 0, 0] = 699
+    oh = utils.one_hot(seg)
+    ref = O.one_hot(seg)
+    assert oh.shape == ref.shape == (2, 700, 5, 6, 7) and oh.dtype == torch.int64
+    assert torch.equal(oh.cpu(), ref)
+    a = torch.randint(0, 5, (1, 1, 4, 4, 4), generator=g)
+    b = torch.randint(10, 15, (1, 1, 4, 4, 4), generator=g)
+    ea, eb = utils.one_hot_subsampled_pair(a, b)
+    assert ea.shape == eb.shape == (1, 0, 4, 4, 4) and ea.dtype == torch.float32
