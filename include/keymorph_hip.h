@@ -343,13 +343,18 @@ size_t kmh_headcom_fwd_bf_ws_bytes(int N, long long V, int Cout, int terms);
 size_t kmh_headcom_bwd_bf_ws_bytes(int N, long long V, int Cin, int Cout, int terms);
 /* scales_out (float[4]) | NULL: the {S, 1/S} range scales of feat and w measured by this call (terms = 2); handed back
  * as scales_in, the backward skips its two measuring passes.  dfeat_scale2 (float[2], ZERO on entry) | NULL: also emits
- * the range scale of dfeat (what kmh_absmax_scale(dfeat) would return) for the consumer convolution's backward. */
+ * the range scale of dfeat (what kmh_absmax_scale(dfeat) would return) for the consumer convolution's backward.
+ * mask (kmh_headcom_mask_words(N, D, H, W, Cout) 32-bit words; 0 words = this geometry has no mask path) | NULL: the
+ * forward also stores [h > 0], 1 bit per (voxel, keypoint channel) -- the ReLU of keymorph/layers.py:99 -- and a backward
+ * handed the same buffer skips recomputing the logits (half its matrix work); with NULL the backward recomputes them. */
+size_t kmh_headcom_mask_words(int N, int D, int H, int W, int Cout);
 int kmh_headcom_fwd_bf(const float* feat, const float* w, const float* bias, float* pts, float* sums, float* sq,
-                       float* scales_out, int N, int D, int H, int W, int Cin, int Cout, int terms, void* ws, void* stream);
+                       float* scales_out, int N, int D, int H, int W, int Cin, int Cout, int terms, unsigned* mask, void* ws,
+                       void* stream);
 int kmh_headcom_bwd_bf(const float* dpts, const float* dpower, const float* feat, const float* w, const float* bias,
                        const float* sums, float* dfeat, float* dw, float* dbias, int N, int D, int H, int W, int Cin,
-                       int Cout, int terms, int mask_dfeat, const float* scales_in, float* dfeat_scale2, void* ws,
-                       void* stream);
+                       int Cout, int terms, int mask_dfeat, const float* scales_in, float* dfeat_scale2,
+                       const unsigned* mask, void* ws, void* stream);
 
 /* caller-side optimizer (scripts/run.py:439 torch.optim.Adam): one fused launch over a flat buffer.
  * g is multiplied by grad_scale first (1/world_size after the RCCL sum all-reduce). */

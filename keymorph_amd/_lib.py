@@ -109,8 +109,9 @@ PROTOS = {
     "kmh_headcom_bwd_ws_bytes": (_sz, [_i, _ll, _i, _i]),
     "kmh_headcom_fwd_bf_ws_bytes": (_sz, [_i, _ll, _i, _i]),
     "kmh_headcom_bwd_bf_ws_bytes": (_sz, [_i, _ll, _i, _i, _i]),
-    "kmh_headcom_fwd_bf": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f]),
-    "kmh_headcom_bwd_bf": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "kmh_headcom_mask_words": (_sz, [_i, _i, _i, _i, _i]),
+    "kmh_headcom_fwd_bf": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
+    "kmh_headcom_bwd_bf": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
     "kmh_headcom_fwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f]),
     "kmh_headcom_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f]),
     "kmh_adam_step": (_i, [_f, _f, _f, _f, _ll, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _f]),

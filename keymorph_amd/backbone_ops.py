@@ -1097,6 +1097,12 @@ def conv_block_batchnorm(x, weight, bias, bn: "torch.nn.modules.batchnorm._Batch
     return y
 
 
+# The forward of the fused head stores [h > 0] (1 bit per voxel and keypoint channel: 0.5 GB for 4 x 128^3 x 512) when a
+# backward can follow, and the backward then skips recomputing the logits.  KEYMORPH_HEAD_MASK=0: always recompute.
+HEAD_MASK = os.environ.get("KEYMORPH_HEAD_MASK", "1") != "0"
+HEAD_STATS = {"mask": 0, "recompute": 0}
+
+
 class _HeadCoM(torch.autograd.Function):
     """pts = CenterOfMass3d('ij')(conv1x1(feat) + b) without the heat-map (csrc/headcom.hip); the second output is
     power = sum relu(h) per channel (keymorph/model.py:96-109), differentiable through the same backward pass."""
@@ -1116,9 +1122,14 @@ class _HeadCoM(torch.autograd.Function):
             terms = _HEAD_TERMS[CONV_MODE]
             ws = workspace(int(lib.kmh_headcom_fwd_bf_ws_bytes(N, D * H * W, Cout, terms)), feat.device, "head")
             hsc = _f32((4,), feat.device) if terms == 2 else None    # feat / filter range scales, re-used by the backward
+            # [h > 0] bits for the backward (it then skips recomputing the logits): only when a backward can follow
+            nmask = int(lib.kmh_headcom_mask_words(N, D, H, W, Cout)) if (HEAD_MASK and any(ctx.needs_input_grad[:3])) else 0
+            hmask = torch.empty(nmask, dtype=torch.int32, device=feat.device) if nmask else None
             check(lib.kmh_headcom_fwd_bf(_p(feat), _p(w), _p(b), _p(pts), _p(sums), None, _p(hsc), N, D, H, W, Cin, Cout,
-                                         terms, _p(ws), _stream()), "kmh_headcom_fwd_bf")
+                                         terms, _p(hmask), _p(ws), _stream()), "kmh_headcom_fwd_bf")
             ctx.hsc = hsc
+            ctx.hmask = hmask
+            HEAD_STATS["mask" if nmask else "recompute"] += 1
         else:
             ws = workspace(int(lib.kmh_headcom_fwd_ws_bytes(N, D * H * W, Cout)), feat.device, "head")
             check(lib.kmh_headcom_fwd(_p(feat), _p(w), _p(b), _p(pts), _p(sums), None, N, D, H, W, Cin, Cout, _p(ws),
@@ -1147,7 +1158,7 @@ class _HeadCoM(torch.autograd.Function):
                    if (terms == 2 and dfeat is not None) else None)
             check(lib.kmh_headcom_bwd_bf(_p(dpts), _p(dpower), _p(feat), _p(w), _p(b), _p(sums), _p(dfeat), _p(dw), _p(db), N, D, H,
                                          W, Cin, Cout, terms, ctx.mask_dfeat, _p(getattr(ctx, "hsc", None)), _p(dsc),
-                                         _p(ws), _stream()), "kmh_headcom_bwd_bf")
+                                         _p(getattr(ctx, "hmask", None)), _p(ws), _stream()), "kmh_headcom_bwd_bf")
             _tag_grad_scale(dfeat, dsc)
         else:
             ws = workspace(int(lib.kmh_headcom_bwd_ws_bytes(N, D * H * W, Cin, Cout)), feat.device, "head")
@@ -1174,7 +1185,7 @@ def head_moments(feat: Tensor, w: Tensor, b: Optional[Tensor]):
             terms = _HEAD_TERMS[CONV_MODE]
             ws = workspace(int(lib.kmh_headcom_fwd_bf_ws_bytes(N, D * H * W, Cout, terms)), feat.device, "head")
             check(lib.kmh_headcom_fwd_bf(_p(feat), _p(w), _p(b), _p(pts), _p(sums), _p(sq), None, N, D, H, W, Cin, Cout,
-                                         terms, _p(ws), _stream()), "kmh_headcom_fwd_bf")
+                                         terms, None, _p(ws), _stream()), "kmh_headcom_fwd_bf")
         else:
             ws = workspace(int(lib.kmh_headcom_fwd_ws_bytes(N, D * H * W, Cout)), feat.device, "head")
             check(lib.kmh_headcom_fwd(_p(feat), _p(w), _p(b), _p(pts), _p(sums), _p(sq), N, D, H, W, Cin, Cout, _p(ws),

@@ -356,6 +356,14 @@ typedef kmh_bf16x8 bf16x8;     // 8 x 16-bit fragment: bf16 (TERMS == 3) or rang
 __device__ __forceinline__ int sig5(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// Sign mask of the logits ([h > 0], 1 bit per (voxel, keypoint channel)), written by the ROWS forward kernel when the
+// caller wants a backward pass and read by the two mask backward kernels instead of recomputing the logits GEMM there:
+//   mask[(n V + v) / 32][CoutP] 32-bit words, bit b of the word of channel k = voxel 32 * block + b; inside a 32-channel
+//   block the word of channel k sits at 2 r + h with k & 31 = (r & 3) + 8 (r >> 2) + 4 h, i.e. the two channels that
+//   register r of an accumulator tile holds in its lane halves are ONE aligned 64-bit word -- in the dfeat kernel
+//   (lane = voxel, register = channel) that word, scalar-loaded, is directly v_cndmask's lane mask.
+__device__ __forceinline__ int head_mask_index(int k) { return 2 * ((k & 3) + 4 * ((k >> 3) & 3)) + ((k >> 2) & 1); }
+
 template <int TERMS>
 __device__ __forceinline__ void split4(const float4 v, uint2 out[TERMS]) {
   float r[4] = {v.x, v.y, v.z, v.w};
@@ -431,7 +439,7 @@ __device__ __forceinline__ void feat_fetch(FeatRegs<VTT, NTHR>& r, const float* 
     }
   }
 }
-template <int TERMS, int VTT, int NTHR, bool TRANSPOSED>
+template <int TERMS, int VTT, int NTHR, bool TRANSPOSED, bool PLAIN = true>
 __device__ __forceinline__ void feat_commit(const FeatRegs<VTT, NTHR>& r, long long v0, long long V, Dims d,
                                             unsigned char* sF, unsigned char* sFT, float4* sC, int tid, float sFs,
                                             bool coords);
@@ -444,7 +452,7 @@ __device__ __forceinline__ void stage_feat_bf(const float* __restrict__ feat, lo
   feat_commit<TERMS, VTT, NTHR, TRANSPOSED>(r, v0, V, d, sF, sFT, sC, tid, sFs, true);
 }
 
-template <int TERMS, int VTT, int NTHR, bool TRANSPOSED>
+template <int TERMS, int VTT, int NTHR, bool TRANSPOSED, bool PLAIN>
 __device__ __forceinline__ void feat_commit(const FeatRegs<VTT, NTHR>& r, long long v0, long long V, Dims d,
                                             unsigned char* sF, unsigned char* sFT, float4* sC, int tid, float sFs,
                                             bool coords) {
@@ -459,10 +467,12 @@ __device__ __forceinline__ void feat_commit(const FeatRegs<VTT, NTHR>& r, long l
     uint2 s0[TERMS], s1[TERMS];
     split4<TERMS>(x0, s0);
     split4<TERMS>(x1, s1);
+    if (PLAIN) {
 #pragma unroll
-    for (int t = 0; t < TERMS; ++t) {
-      *reinterpret_cast<uint2*>(sF + t * (VTT * 128) + swz(v, c4 >> 1) + (c4 & 1) * 8) = s0[t];
-      *reinterpret_cast<uint2*>(sF + t * (VTT * 128) + swz(v + 1, c4 >> 1) + (c4 & 1) * 8) = s1[t];
+      for (int t = 0; t < TERMS; ++t) {
+        *reinterpret_cast<uint2*>(sF + t * (VTT * 128) + swz(v, c4 >> 1) + (c4 & 1) * 8) = s0[t];
+        *reinterpret_cast<uint2*>(sF + t * (VTT * 128) + swz(v + 1, c4 >> 1) + (c4 & 1) * 8) = s1[t];
+      }
     }
     if (TRANSPOSED) {
       const int pos = (v & ~31) | sig5(v & 31);        // v even -> pos even, voxel v+1 sits at pos+1
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 1) void headcom_fwd_bf_ker
                                                                  double* __restrict__ partial, long long V, int Cin,
                                                                  int Cout, int CoutP, Dims d, int tiles_per_slab,
                                                                  int nslab, int ngroups, const float* __restrict__ hs,
-                                                                 int want_sq) {
+                                                                 int want_sq, unsigned* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
   constexpr int FBUF = TERMS * FVT * 128 + FVT * 16;                   // one buffer: sF [TERMS][FVT][128 B] + sC [FVT]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -609,6 +619,20 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 1) void headcom_fwd_bf_ker
         S[1] = fmaf(R, (float)zb, S[1]);
         S[2] = fmaf(R, (float)yb, S[2]);
         S[3] += fmaf(R, (float)(xb + 4 * lh), T);
+        if (mask) {            // [h > 0] of this block for the backward kernels (head_mask_index): two VALU per logit
+          unsigned bits = 0u;
+#pragma unroll
+          for (int q = 3; q >= 0; --q) {
+#pragma unroll
+            for (int j = 3; j >= 0; --j)
+              asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(acc[4 * q + j]) : "vcc");
+            if (q) bits <<= 4;                                           // register 4 q + j = voxel row 8 q + j (+ 4 lh)
+          }
+          bits <<= 4 * lh;
+          bits |= __shfl_xor(bits, 32, 64);
+          if (lh == 0)
+            mask[(((long long)n * V + tile * FVT) / 32 + vb) * CoutP + (co - li) + head_mask_index(li)] = bits;
+        }
         continue;
       }
 #pragma unroll
@@ -960,6 +984,259 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_bf_kernel(const fl
   if (amax) kmh_absmax::publish(mxo, amax);      // the consumer convolution's range scale, for free
 }
 
+// =============================================================================================
+// Mask variants of the two backward kernels (ROWS geometry: W % 32 == 0, V % FVT == 0).  The forward kernel stored
+// [h > 0] (head_mask_index), so neither kernel recomputes the logits: no filter fragments / plain feature image, half the
+// MFMAs, and dh is one fma on the block's row constants plus the mask.
+//
+// dW / db: lane = channel, register r = voxel row.  The lane's 32-bit word of the block holds its 16 voxels at bits
+// (r & 3) + 8 (r >> 2) + 4 lh: v_bfe_i32 (0 / -1) + v_and per element.
+// WIDE: Cin > 32 (compile time: a run-time test around the second accumulator tile's products makes the compiler shuffle
+// whole accumulator tiles between registers).
+template <int TERMS, int NWV, bool WIDE>
+__global__ __launch_bounds__(64 * NWV, 2) void headcom_bwd_w_mask_kernel(
+    const float* __restrict__ feat, const unsigned* __restrict__ mask, const float* __restrict__ g,
+    float* __restrict__ pw /* (nslab, Cout, Cin) */, float* __restrict__ pb /* (nslab, Cout) */, int N, long long V,
+    int Cin, int Cout, int CoutP, Dims d, int tiles_per_slab, int ngroups, const float* __restrict__ hs,
+    const int* __restrict__ gate, int want) {
+  if (gate && *gate != want) return;         // the other arithmetic runs this backward (head_dh_scale_kernel)
+  extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+  constexpr int WBUF = TERMS * 64 * 128;     // one buffer: sFT [TERMS][64 ci][128 B] (columns = sigma(voxel))
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int item = xcd_remap(blockIdx.x, gridDim.x);
+  const int grp = item % ngroups, slab = item / ngroups;
+  constexpr int NT_ = 64 * NWV;
+  const int co = grp * (32 * NWV) + 32 * wv + li;
+  const float sFs = hs[0], sDh = hs[4], desc_w = hs[5] * hs[1];
+  f32x16 dw[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dw[ct][r] = 0.f;
+  float db = 0.f;
+  const long long tiles_per_n = V / WVT, ntiles = tiles_per_n * N;
+  long long t_beg = (long long)slab * tiles_per_slab, t_end = t_beg + tiles_per_slab;
+  if (t_end > ntiles) t_end = ntiles;
+  FeatRegs<WVT, NT_> pre;                    // the next tile's features, in flight under this tile's MFMAs
+  int n = t_beg < t_end ? (int)(t_beg / tiles_per_n) : 0;
+  long long v0 = (t_beg - (long long)n * tiles_per_n) * WVT;
+  const unsigned* mrow = mask + (co - li) + head_mask_index(li);
+  auto commit = [&](long long tile, long long vfirst) {
+    unsigned char* b = hsm + (int)((tile - t_beg) & 1) * WBUF;
+    feat_commit<TERMS, WVT, NT_, true, false>(pre, vfirst, V, d, nullptr, b, nullptr, tid, sFs, false);
+  };
+  auto mfetch = [&](int nn, long long vv, unsigned out[2]) {
+    const long long nb = ((long long)nn * V + vv) >> 5;
+    out[0] = mrow[nb * CoutP];
+    out[1] = mrow[(nb + 1) * CoutP];
+  };
+  auto step = [&](int& nn, long long& vv) { vv += WVT; if (vv >= V) { vv = 0; ++nn; } };
+  int n_next = n;
+  long long v_next = v0;
+  step(n_next, v_next);
+  unsigned mcur[2] = {0u, 0u}, mnext[2] = {0u, 0u};
+  if (t_beg < t_end) {
+    feat_fetch<WVT, NT_>(pre, feat + (long long)n * V * Cin, v0, V, Cin, tid);
+    mfetch(n, v0, mcur);
+    commit(t_beg, v0);
+    if (t_beg + 1 < t_end) {
+      feat_fetch<WVT, NT_>(pre, feat + (long long)n_next * V * Cin, v_next, V, Cin, tid);
+      mfetch(n_next, v_next, mnext);
+    }
+  }
+  __syncthreads();
+  RowCursor cur;
+  cur.set(v0, d);
+  const float iz = d.D > 1 ? 1.f / (float)(d.D - 1) : 0.f, iy = d.H > 1 ? 1.f / (float)(d.H - 1) : 0.f,
+              ix = d.W > 1 ? 1.f / (float)(d.W - 1) : 0.f;
+  for (long long tile = t_beg; tile < t_end; ++tile) {
+    const unsigned char* sFT = hsm + (int)((tile - t_beg) & 1) * WBUF;
+    const float4 gv = co < Cout ? *reinterpret_cast<const float4*>(g + ((long long)n * Cout + co) * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float gxs = gv.w * ix * sDh;                               // per x step, in the operand's range scale
+#pragma unroll
+    for (int vb = 0; vb < WVT / 32; ++vb) {
+      const int xb = cur.x, yb = cur.y, zb = cur.z;                  // wave-uniform origin of block v0 + 32 vb
+      cur.advance32(d);
+      const float G = (gv.x + gv.y * ((float)zb * iz) + gv.z * ((float)yb * iy)) * sDh + gxs * (float)(xb + 4 * lh);
+      const int w = (int)(mcur[vb] >> (4 * lh));
+      float dh[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pos = (r & 3) + 8 * (r >> 2);
+        unsigned m;                                                   // 0 or ~0 (v_bfe_i32; kept opaque: the compiler
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(w), "n"(pos));     // would turn "& m" back into and + cmp + cndmask)
+        dh[r] = __uint_as_float(__float_as_uint(fmaf(gxs, (float)pos, G)) & m);
+        db += dh[r];                                                 // scaled by sDh: undone when the partial is written
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 a[TERMS];
+        split8<TERMS>(dh + 8 * s2, a);
+#pragma unroll
+        for (int ct = 0; ct < (WIDE ? 2 : 1); ++ct) {
+          bf16x8 b[TERMS];
+#pragma unroll
+          for (int t = 0; t < TERMS; ++t)
+            b[t] = *reinterpret_cast<const bf16x8*>(sFT + t * (64 * 128) + swz(32 * ct + li, 4 * vb + 2 * s2 + lh));
+          dw[ct] = mfma_split<TERMS>(a, b, dw[ct]);
+        }
+      }
+    }
+    n = n_next;
+    v0 = v_next;
+    step(n_next, v_next);
+    mcur[0] = mnext[0]; mcur[1] = mnext[1];
+    if (tile + 1 < t_end) {
+      commit(tile + 1, v0);
+      if (tile + 2 < t_end) {
+        feat_fetch<WVT, NT_>(pre, feat + (long long)n_next * V * Cin, v_next, V, Cin, tid);
+        mfetch(n_next, v_next, mnext);
+      }
+    }
+    __syncthreads();
+  }
+  float* ow = pw + (long long)slab * Cout * Cin;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int c = 32 * ct + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = grp * (32 * NWV) + 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (k < Cout && c < Cin) ow[(long long)k * Cin + c] = dw[ct][r] * desc_w;
+    }
+  }
+  db += __shfl_xor(db, 32, 64);
+  db /= sDh;                                               // a power of two (1 for TERMS == 3)
+  if (lh == 0 && co < Cout) pb[(long long)slab * Cout + co] = db;
+}
+
+// dfeat: workgroup = 256 voxels (8 waves x one 32-voxel block of an x row), loops over 64-channel blocks of W^T.
+// lane = voxel, register r = channel row: the block's mask words of channels (r, r + 4) are one aligned 64-bit word
+// at a wave-uniform address -- a scalar load whose result is v_cndmask's lane mask (one VALU per element); the
+// gradient coefficient is fma(B[k], cx, A[k]) with A[k] = (g0 + gz cz + gy cy) S_dh staged per (wave, channel).
+template <int TERMS, bool WIDE>
+__global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_mask_kernel(
+    const float* __restrict__ feat, const __bf16* __restrict__ wt, const unsigned* __restrict__ mask,
+    const float* __restrict__ g, float* __restrict__ dfeat, long long V, int Cin, int Cout, int CoutP, Dims d,
+    const float* __restrict__ hs, int mask_dfeat, unsigned* __restrict__ amax, const int* __restrict__ gate, int want) {
+  if (gate && *gate != want) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+  constexpr int IMG = TERMS * 64 * 128;            // W^T block: [TERMS][64 ci][128 B]
+  constexpr int BUF = IMG + 8 * WBLK * 8;          // + (A, B) per (wave, channel of the block)
+  constexpr int NLD = (IMG / 16 + BF_TPB - 1) / BF_TPB;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.y;
+  const long long vw = (long long)blockIdx.x * 256 + 32 * wv;          // the wave's block (V % 32 == 0: whole waves)
+  const bool wok = vw < V;
+  const long long v = vw + li;
+  const float* fn = feat + (long long)n * V * Cin;
+  const float sDh = hs[4], desc_f = hs[5] * hs[3];
+  float cz = 0.f, cy = 0.f, cx = 0.f;
+  if (wok) {
+    const unsigned u = (unsigned)vw, row = u / (unsigned)d.W, x0 = u - row * (unsigned)d.W;
+    const unsigned z = row / (unsigned)d.H, y = row - z * (unsigned)d.H;
+    cz = d.D > 1 ? (float)z / (float)(d.D - 1) : 0.f;
+    cy = d.H > 1 ? (float)y / (float)(d.H - 1) : 0.f;
+    cx = d.W > 1 ? (float)(x0 + li) / (float)(d.W - 1) : 0.f;
+  }
+  const unsigned long long* mp =
+      reinterpret_cast<const unsigned long long*>(mask + ((((long long)n * V + (wok ? vw : 0)) >> 5) * CoutP));
+  f32x16 acc2[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
+  const int nblk = CoutP / WBLK;
+  uint4 pre[NLD];
+  auto fetch = [&](int blk) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + k * BF_TPB;
+      pre[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < IMG / 16) {
+        const int chunk = i & 7, row = (i >> 3) & 63, t = i >> 9;
+        pre[k] = *reinterpret_cast<const uint4*>(wt + ((long long)t * 64 + row) * CoutP + blk * WBLK + chunk * 8);
+      }
+    }
+  };
+  auto commit = [&](int blk, unsigned char* buf) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + k * BF_TPB;
+      if (i < IMG / 16) {
+        const int chunk = i & 7, row = (i >> 3) & 63, t = i >> 9;
+        *reinterpret_cast<uint4*>(buf + t * (64 * 128) + swz(row, chunk)) = pre[k];
+      }
+    }
+    const int k = blk * WBLK + lane;
+    float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < Cout) gq = *reinterpret_cast<const float4*>(g + ((long long)n * Cout + k) * 4);
+    reinterpret_cast<float2*>(buf + IMG)[wv * WBLK + lane] =
+        make_float2((gq.x + gq.y * cz + gq.z * cy) * sDh, gq.w * sDh);
+  };
+  fetch(0);
+  commit(0, hsm);
+  __syncthreads();
+  for (int blk = 0; blk < nblk; ++blk) {
+    unsigned char* buf = hsm + (blk & 1) * BUF;
+    if (blk + 1 < nblk) fetch(blk + 1);
+    const unsigned char* sWt = buf;
+    const float2* sAB = reinterpret_cast<const float2*>(buf + IMG) + wv * WBLK;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {                  // 32-channel tile of the block
+      unsigned long long mk[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mk[r] = mp[(blk * WBLK + 32 * m) / 2 + r];   // (a wave past the volume: block 0's, unused)
+      float dh[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float2 ab = sAB[32 * m + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        const float gd = fmaf(ab.y, cx, ab.x);
+        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(dh[r]) : "v"(gd), "s"(mk[r]));
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 b[TERMS];
+        split8<TERMS>(dh + 8 * s2, b);
+#pragma unroll
+        for (int mt = 0; mt < (WIDE ? 2 : 1); ++mt) {
+          bf16x8 a[TERMS];
+#pragma unroll
+          for (int t = 0; t < TERMS; ++t)
+            a[t] = *reinterpret_cast<const bf16x8*>(sWt + t * (64 * 128) + swz(32 * mt + li, 4 * m + 2 * s2 + lh));
+          acc2[mt] = mfma_split<TERMS>(a, b, acc2[mt]);
+        }
+      }
+    }
+    if (blk + 1 < nblk) commit(blk + 1, hsm + ((blk + 1) & 1) * BUF);
+    __syncthreads();
+  }
+  float mxo = 0.f;
+  if (wok) {
+    float* o = dfeat + ((long long)n * V + v) * Cin;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 32 * mt + 8 * q + 4 * lh;
+        if (c < Cin) {
+          float4 r = make_float4(acc2[mt][4 * q] * desc_f, acc2[mt][4 * q + 1] * desc_f, acc2[mt][4 * q + 2] * desc_f,
+                                 acc2[mt][4 * q + 3] * desc_f);
+          if (mask_dfeat) {
+            const float4 f = *reinterpret_cast<const float4*>(fn + v * Cin + c);
+            r.x = f.x > 0.f ? r.x : 0.f; r.y = f.y > 0.f ? r.y : 0.f; r.z = f.z > 0.f ? r.z : 0.f; r.w = f.w > 0.f ? r.w : 0.f;
+          }
+          *reinterpret_cast<float4*>(o + c) = r;
+          mxo = fmaxf(fmaxf(mxo, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+        }
+      }
+  }
+  if (amax) kmh_absmax::publish(mxo, amax);
+}
+
+
 static int fwd_slabs(long long V, int* tps) {
   const long long ntiles = (V + VT - 1) / VT;
   long long t = (ntiles + 255) / 256;
@@ -1093,6 +1370,12 @@ static int head_scales(const float* feat, long long nfeat, const float* w, long 
   return KMH_LAUNCH_CHECK();
 }
 
+// the ROWS geometry of the split-operand kernels: 32-voxel blocks are pieces of one x row, no padding voxels
+static bool head_rows_ok(int D, int H, int W) {
+  const long long V = (long long)D * H * W;
+  return W % 32 == 0 && V % FVT == 0 && V < (1ll << 31);
+}
+
 struct HeadBfPlan {
   int CoutP, nwv, ngroups, nwv_w, ngroups_w, nslab_f, tps_f, nslab_w, tps_w;
   size_t img_bytes;     // the three pre-split weight images
@@ -1136,7 +1419,7 @@ static int head_pack(const float* w, int Cout, int Cin, const HeadBfPlan& p, voi
 
 template <int TERMS>
 static int head_fwd_bf(const float* feat, const float* w, const float* bias, float* pts, float* sums, float* sq, float* scales_out, int N,
-                       int D, int H, int W, int Cin, int Cout, void* ws, hipStream_t s) {
+                       int D, int H, int W, int Cin, int Cout, unsigned* mask, void* ws, hipStream_t s) {
   const long long V = (long long)D * H * W;
   const HeadBfPlan p = head_bf_plan(N, V, Cout, TERMS);
   double* partial = (double*)ws;
@@ -1148,13 +1431,14 @@ static int head_fwd_bf(const float* feat, const float* w, const float* bias, flo
   if (rc) return rc;
   Dims d{D, H, W};
   const size_t lds = 2 * ((size_t)TERMS * FVT * 128 + FVT * sizeof(float4));   // double buffered
-  const bool rows = W % 32 == 0 && V % FVT == 0 && V < (1ll << 31);
+  const bool rows = head_rows_ok(D, H, W);
+  if (mask && !rows) return -22;             // kmh_headcom_mask_words said 0 for this geometry
   auto kern = p.nwv == 16 ? (rows ? headcom_fwd_bf_kernel<TERMS, true, 16> : headcom_fwd_bf_kernel<TERMS, false, 16>)
                           : (rows ? headcom_fwd_bf_kernel<TERMS, true, 4> : headcom_fwd_bf_kernel<TERMS, false, 4>);
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   kern<<<dim3(p.nslab_f * p.ngroups, N), 64 * p.nwv, lds, s>>>(feat, (const __bf16*)img, bias, partial, V, Cin, Cout, p.CoutP, d,
-                                                         p.tps_f, p.nslab_f, p.ngroups, hs, sq != nullptr);
+                                                         p.tps_f, p.nslab_f, p.ngroups, hs, sq != nullptr, mask);
   headcom_final_kernel<<<ceil_div(N * Cout, 64), 64, 0, s>>>(partial, p.nslab_f, N * Cout, pts, sums, sq);
   if (scales_out) head_scales_copy_kernel<<<1, 64, 0, s>>>(hs, scales_out);
   return KMH_LAUNCH_CHECK();
@@ -1163,8 +1447,10 @@ static int head_fwd_bf(const float* feat, const float* w, const float* bias, flo
 template <int TERMS>
 static int head_bwd_bf(const float* dpts, const float* dpower, const float* feat, const float* w, const float* bias, const float* sums,
                        float* dfeat, float* dw, float* dbias, int N, int D, int H, int W, int Cin, int Cout,
-                       int mask_dfeat, const float* scales_in, float* dfeat_scale2, void* ws, hipStream_t s) {
+                       int mask_dfeat, const float* scales_in, float* dfeat_scale2, const unsigned* mask, void* ws,
+                       hipStream_t s) {
   const long long V = (long long)D * H * W;
+  if (mask && !head_rows_ok(D, H, W)) return -22;
   const HeadBfPlan p = head_bf_plan(N, V, Cout, TERMS);
   char* base = (char*)ws;
   float* g = (float*)base;
@@ -1192,7 +1478,15 @@ static int head_bwd_bf(const float* dpts, const float* dpower, const float* feat
     const __bf16* wk = (const __bf16*)img_;
     const __bf16* wkp = wk + (size_t)T * pl.CoutP * 64;
     const __bf16* wt = wkp + (size_t)T * pl.CoutP * 64;
-    if (dfeat) {
+    if (dfeat && mask) {
+      const size_t lds = 2 * ((size_t)T * 64 * 128 + 8 * WBLK * 8);
+      auto kern = Cin > 32 ? headcom_bwd_feat_mask_kernel<T, true> : headcom_bwd_feat_mask_kernel<T, false>;
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      kern<<<dim3(ceil_div(V, 256), N), BF_TPB, lds, s>>>(
+          feat, wt, mask, g, dfeat, V, Cin, Cout, pl.CoutP, d, hs_, mask_dfeat, reinterpret_cast<unsigned*>(dfeat_scale2),
+          gate, want);
+    } else if (dfeat) {
       const size_t lds = 2 * ((size_t)2 * T * 64 * 128 + WBLK * 32);
       hipError_t e = hipFuncSetAttribute((const void*)headcom_bwd_feat_bf_kernel<T>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1201,7 +1495,15 @@ static int head_bwd_bf(const float* dpts, const float* dpower, const float* feat
           feat, wkp, wt, bias, g, dfeat, V, Cin, Cout, pl.CoutP, d, hs_, mask_dfeat,
           reinterpret_cast<unsigned*>(dfeat_scale2), gate, want);
     }
-    if (dw) {
+    if (dw && mask) {
+      const size_t lds = 2 * ((size_t)T * 64 * 128);                               // double buffered
+      auto kern = pl.nwv_w == 8 ? (Cin > 32 ? headcom_bwd_w_mask_kernel<T, 8, true> : headcom_bwd_w_mask_kernel<T, 8, false>)
+                                : (Cin > 32 ? headcom_bwd_w_mask_kernel<T, 4, true> : headcom_bwd_w_mask_kernel<T, 4, false>);
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      kern<<<dim3(pl.nslab_w * pl.ngroups_w), 64 * pl.nwv_w, lds, s>>>(feat, mask, g, pw, pb, N, V, Cin, Cout, pl.CoutP, d,
+                                                                      pl.tps_w, pl.ngroups_w, hs_, gate, want);
+    } else if (dw) {
       const size_t lds = 2 * ((size_t)2 * T * WVT * 128 + WVT * sizeof(float4));   // double buffered
       const bool rows = W % 32 == 0 && V % WVT == 0 && V < (1ll << 31);
       auto kern = pl.nwv_w == 8 ? (rows ? headcom_bwd_w_bf_kernel<T, true, 8> : headcom_bwd_w_bf_kernel<T, false, 8>)
@@ -1246,20 +1548,25 @@ KMH_API size_t kmh_headcom_bwd_bf_ws_bytes(int N, long long V, int Cin, int Cout
 }
 
 /* same contracts as kmh_headcom_fwd / kmh_headcom_bwd; Cin % 4 == 0, Cin <= 64 */
+KMH_API size_t kmh_headcom_mask_words(int N, int D, int H, int W, int Cout) {
+  if (!head_rows_ok(D, H, W)) return 0;
+  return (size_t)N * ((size_t)D * H * W / 32) * (size_t)(ceil_div(Cout, GC) * GC);
+}
 KMH_API int kmh_headcom_fwd_bf(const float* feat, const float* w, const float* bias, float* pts, float* sums, float* sq,
-                               float* scales_out, int N, int D, int H, int W, int Cin, int Cout, int terms, void* ws,
-                               void* stream) {
+                               float* scales_out, int N, int D, int H, int W, int Cin, int Cout, int terms, unsigned* mask,
+                               void* ws, void* stream) {
   if (Cin > 64 || (Cin & 3) || (terms != 2 && terms != 3)) return -22;
-  return terms == 3 ? head_fwd_bf<3>(feat, w, bias, pts, sums, sq, scales_out, N, D, H, W, Cin, Cout, ws, (hipStream_t)stream)
-                    : head_fwd_bf<2>(feat, w, bias, pts, sums, sq, scales_out, N, D, H, W, Cin, Cout, ws, (hipStream_t)stream);
+  return terms == 3
+             ? head_fwd_bf<3>(feat, w, bias, pts, sums, sq, scales_out, N, D, H, W, Cin, Cout, mask, ws, (hipStream_t)stream)
+             : head_fwd_bf<2>(feat, w, bias, pts, sums, sq, scales_out, N, D, H, W, Cin, Cout, mask, ws, (hipStream_t)stream);
 }
 KMH_API int kmh_headcom_bwd_bf(const float* dpts, const float* dpower, const float* feat, const float* w, const float* bias,
                                const float* sums, float* dfeat, float* dw, float* dbias, int N, int D, int H, int W,
                                int Cin, int Cout, int terms, int mask_dfeat, const float* scales_in,
-                               float* dfeat_scale2, void* ws, void* stream) {
+                               float* dfeat_scale2, const unsigned* mask, void* ws, void* stream) {
   if (Cin > 64 || (Cin & 3) || (terms != 2 && terms != 3)) return -22;
   return terms == 3 ? head_bwd_bf<3>(dpts, dpower, feat, w, bias, sums, dfeat, dw, dbias, N, D, H, W, Cin, Cout,
-                                     mask_dfeat, scales_in, dfeat_scale2, ws, (hipStream_t)stream)
+                                     mask_dfeat, scales_in, dfeat_scale2, mask, ws, (hipStream_t)stream)
                     : head_bwd_bf<2>(dpts, dpower, feat, w, bias, sums, dfeat, dw, dbias, N, D, H, W, Cin, Cout,
-                                     mask_dfeat, scales_in, dfeat_scale2, ws, (hipStream_t)stream);
+                                     mask_dfeat, scales_in, dfeat_scale2, mask, ws, (hipStream_t)stream);
 }

@@ -375,6 +375,53 @@ def test_fused_head_matches_unfused(cfg):
         B.set_conv_mode(old)
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 512, (8, 16, 64)), (1, 64, 200, (4, 8, 128)), (3, 32, 96, (6, 8, 32)),
+                                 (2, 24, 130, (2, 4, 96))])
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
+def test_fused_head_mask_backward(cfg, mode):
+    """On whole-x-row geometries the forward stores [h > 0] and the backward kernels skip recomputing the logits
+    (csrc/headcom.hip, headcom_bwd_{w,feat}_mask_kernel).  The mask backward must (i) actually run, (ii) agree with the
+    recomputing kernels to rounding (same sign pattern, dh coefficients rounded differently) and (iii) with fp64 autograd
+    of the materialised heat-map (keymorph/layers.py:92-134 on keymorph/unet3d/model.py:387-391)."""
+    from keymorph_amd import backbone_ops as B
+    from oracle import keymorph_oracle as O
+    N, Cin, Cout, dims = cfg
+    g = gen(31)
+    x = torch.randn(N, *dims, Cin, generator=g).abs()           # a ReLU output, like the decoder's last block
+    w = torch.randn(Cout, Cin, 1, 1, 1, generator=g) / np.sqrt(Cin)
+    b = 0.3 * torch.randn(Cout, generator=g)
+    cot, cw = torch.randn(N, Cout, 3, generator=g), torch.randn(N, Cout, generator=g)
+    R = [t.clone().double().requires_grad_(True) for t in (x, w, b)]
+    h = F.conv3d(ncdhw(R[0]), R[1], R[2])
+    ((O.center_of_mass(h, "ij") * cot.double()).sum() + (F.relu(h).flatten(2).sum(-1) * cw.double()).sum()).backward()
+    old, old_mask = B.CONV_MODE, B.HEAD_MASK
+    grads = {}
+    try:
+        B.set_conv_mode(mode)
+        for use_mask in (True, False):
+            B.HEAD_MASK = use_mask
+            before = dict(B.HEAD_STATS)
+            A = [t.to(DEV).requires_grad_(True) for t in (x, w, b)]
+            pa, wa = B.head_com_power(*A, feat_from_relu=False)
+            ((pa * cot.to(DEV)).sum() + (wa * cw.to(DEV)).sum()).backward()
+            assert B.HEAD_STATS["mask" if use_mask else "recompute"] == before["mask" if use_mask else "recompute"] + 1
+            grads[use_mask] = [t.grad.cpu().double() for t in A]
+            close(pa, O.center_of_mass(h, "ij").detach(), 5e-6, 1e-5)
+        # no-grad forward: no mask is written
+        before = dict(B.HEAD_STATS)
+        B.HEAD_MASK = True
+        with torch.no_grad():
+            B.head_com(*[t.to(DEV) for t in (x, w, b)])
+        assert B.HEAD_STATS["mask"] == before["mask"]
+    finally:
+        B.set_conv_mode(old)
+        B.HEAD_MASK = old_mask
+    for gm, gr, ref in zip(grads[True], grads[False], R):
+        rn = float(ref.grad.norm())
+        assert float((gm - gr).norm()) < 2e-6 * rn, ("mask vs recompute", float((gm - gr).norm()) / rn)
+        assert float((gm - ref.grad).norm()) < 2e-5 * rn, ("mask vs fp64", float((gm - ref.grad).norm()) / rn)
+
+
 @pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "f32"])
 def test_fused_head_power_output_and_gradient(mode):
     """second output of the fused head: power = sum relu(h) (keymorph/model.py:96-109) and its gradient, which rides
