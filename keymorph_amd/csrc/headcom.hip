@@ -366,6 +366,14 @@ __device__ __forceinline__ int head_mask_index(int k) { return 2 * ((k & 3) + 4 
 
 template <int TERMS>
 __device__ __forceinline__ void split4(const float4 v, uint2 out[TERMS]) {
+  if constexpr (TERMS == 2) {          // packed conversions (common.h split_pair): 3 VALU per pair
+    unsigned a[2], b[2];
+    split_pair<2>(v.x, v.y, a);
+    split_pair<2>(v.z, v.w, b);
+    out[0] = make_uint2(a[0], b[0]);
+    out[1] = make_uint2(a[1], b[1]);
+    return;
+  }
   float r[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int t = 0; t < TERMS; ++t) {
@@ -1013,7 +1021,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void headcom_bwd_w_mask_kernel(
   for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dw[ct][r] = 0.f;
-  float db = 0.f;
+  kmh_f2 db2 = {0.f, 0.f};
   const long long tiles_per_n = V / WVT, ntiles = tiles_per_n * N;
   long long t_beg = (long long)slab * tiles_per_slab, t_end = t_beg + tiles_per_slab;
   if (t_end > ntiles) t_end = ntiles;
@@ -1067,8 +1075,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void headcom_bwd_w_mask_kernel(
         unsigned m;                                                   // 0 or ~0 (v_bfe_i32; kept opaque: the compiler
         asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(w), "n"(pos));     // would turn "& m" back into and + cmp + cndmask)
         dh[r] = __uint_as_float(__float_as_uint(fmaf(gxs, (float)pos, G)) & m);
-        db += dh[r];                                                 // scaled by sDh: undone when the partial is written
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) db2 += kmh_f2{dh[2 * j], dh[2 * j + 1]};     // scaled by sDh: undone when written
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 a[TERMS];
@@ -1106,6 +1115,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void headcom_bwd_w_mask_kernel(
       if (k < Cout && c < Cin) ow[(long long)k * Cin + c] = dw[ct][r] * desc_w;
     }
   }
+  float db = db2.x + db2.y;
   db += __shfl_xor(db, 32, 64);
   db /= sDh;                                               // a power of two (1 for TERMS == 3)
   if (lh == 0 && co < Cout) pb[(long long)slab * Cout + co] = db;
