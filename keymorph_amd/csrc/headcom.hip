@@ -358,11 +358,10 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 
 // Sign mask of the logits ([h > 0], 1 bit per (voxel, keypoint channel)), written by the ROWS forward kernel when the
 // caller wants a backward pass and read by the two mask backward kernels instead of recomputing the logits GEMM there:
-//   mask[(n V + v) / 32][CoutP] 32-bit words, bit b of the word of channel k = voxel 32 * block + b; inside a 32-channel
-//   block the word of channel k sits at 2 r + h with k & 31 = (r & 3) + 8 (r >> 2) + 4 h, i.e. the two channels that
-//   register r of an accumulator tile holds in its lane halves are ONE aligned 64-bit word -- in the dfeat kernel
-//   (lane = voxel, register = channel) that word, scalar-loaded, is directly v_cndmask's lane mask.
-__device__ __forceinline__ int head_mask_index(int k) { return 2 * ((k & 3) + 4 * ((k >> 3) & 3)) + ((k >> 2) & 1); }
+//   mask[(n V + v) / 32][CoutP] 32-bit words: bit b of word k = [h > 0] of voxel 32 * block + b, channel k.
+// (Scalar loads of these words straight into v_cndmask's lane-mask operand were tried in the dfeat kernel: one VALU per
+// element, but every 64-byte line is a first touch of HBM -- ~1 us exposed per s_load, four per 64-channel block, and the
+// kernel ran at that latency.  The words now ride with the staged filter block, a block ahead.)
 
 template <int TERMS>
 __device__ __forceinline__ void split4(const float4 v, uint2 out[TERMS]) {
@@ -627,7 +626,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 1) void headcom_fwd_bf_ker
         S[1] = fmaf(R, (float)zb, S[1]);
         S[2] = fmaf(R, (float)yb, S[2]);
         S[3] += fmaf(R, (float)(xb + 4 * lh), T);
-        if (mask) {            // [h > 0] of this block for the backward kernels (head_mask_index): two VALU per logit
+        if (mask) {            // [h > 0] of this block for the backward kernels: two VALU per logit
           unsigned bits = 0u;
 #pragma unroll
           for (int q = 3; q >= 0; --q) {
@@ -639,7 +638,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 1) void headcom_fwd_bf_ker
           bits <<= 4 * lh;
           bits |= __shfl_xor(bits, 32, 64);
           if (lh == 0)
-            mask[(((long long)n * V + tile * FVT) / 32 + vb) * CoutP + (co - li) + head_mask_index(li)] = bits;
+            mask[(((long long)n * V + tile * FVT) / 32 + vb) * CoutP + co] = bits;
         }
         continue;
       }
@@ -994,7 +993,7 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_bf_kernel(const fl
 
 // =============================================================================================
 // Mask variants of the two backward kernels (ROWS geometry: W % 32 == 0, V % FVT == 0).  The forward kernel stored
-// [h > 0] (head_mask_index), so neither kernel recomputes the logits: no filter fragments / plain feature image, half the
+// [h > 0], so neither kernel recomputes the logits: no filter fragments / plain feature image, half the
 // MFMAs, and dh is one fma on the block's row constants plus the mask.
 //
 // dW / db: lane = channel, register r = voxel row.  The lane's 32-bit word of the block holds its 16 voxels at bits
@@ -1028,7 +1027,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void headcom_bwd_w_mask_kernel(
   FeatRegs<WVT, NT_> pre;                    // the next tile's features, in flight under this tile's MFMAs
   int n = t_beg < t_end ? (int)(t_beg / tiles_per_n) : 0;
   long long v0 = (t_beg - (long long)n * tiles_per_n) * WVT;
-  const unsigned* mrow = mask + (co - li) + head_mask_index(li);
+  const unsigned* mrow = mask + co;
   auto commit = [&](long long tile, long long vfirst) {
     unsigned char* b = hsm + (int)((tile - t_beg) & 1) * WBUF;
     feat_commit<TERMS, WVT, NT_, true, false>(pre, vfirst, V, d, nullptr, b, nullptr, tid, sFs, false);
@@ -1122,9 +1121,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void headcom_bwd_w_mask_kernel(
 }
 
 // dfeat: workgroup = 256 voxels (8 waves x one 32-voxel block of an x row), loops over 64-channel blocks of W^T.
-// lane = voxel, register r = channel row: the block's mask words of channels (r, r + 4) are one aligned 64-bit word
-// at a wave-uniform address -- a scalar load whose result is v_cndmask's lane mask (one VALU per element); the
-// gradient coefficient is fma(B[k], cx, A[k]) with A[k] = (g0 + gz cz + gy cy) S_dh staged per (wave, channel).
+// lane = voxel, register r = channel row.  Per (wave, channel of the staged block) LDS holds {A, B, mask word}:
+// the gradient coefficient is fma(B[k], cx, A[k]) with A[k] = (g0 + gz cz + gy cy) S_dh, the lane's bit of the word
+// (v_bfe_i32: 0 / ~0) masks it -- one broadcast ds_read_b128 and three VALU per element.  The mask words are fetched
+// with the filter block, one block ahead (registers), like the filter fragments themselves.
 template <int TERMS, bool WIDE>
 __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_mask_kernel(
     const float* __restrict__ feat, const __bf16* __restrict__ wt, const unsigned* __restrict__ mask,
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_mask_kernel(
   if (gate && *gate != want) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
   constexpr int IMG = TERMS * 64 * 128;            // W^T block: [TERMS][64 ci][128 B]
-  constexpr int BUF = IMG + 8 * WBLK * 8;          // + (A, B) per (wave, channel of the block)
+  constexpr int BUF = IMG + 8 * WBLK * 16;         // + {A, B, mask word, -} per (wave, channel of the block)
   constexpr int NLD = (IMG / 16 + BF_TPB - 1) / BF_TPB;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1151,8 +1151,7 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_mask_kernel(
     cy = d.H > 1 ? (float)y / (float)(d.H - 1) : 0.f;
     cx = d.W > 1 ? (float)(x0 + li) / (float)(d.W - 1) : 0.f;
   }
-  const unsigned long long* mp =
-      reinterpret_cast<const unsigned long long*>(mask + ((((long long)n * V + (wok ? vw : 0)) >> 5) * CoutP));
+  const unsigned* mrow = mask + ((((long long)n * V + (wok ? vw : 0)) >> 5) * CoutP) + lane;   // the wave's block
   f32x16 acc2[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -1160,6 +1159,7 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_mask_kernel(
     for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
   const int nblk = CoutP / WBLK;
   uint4 pre[NLD];
+  unsigned mpre;
   auto fetch = [&](int blk) {
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
@@ -1170,6 +1170,7 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_mask_kernel(
         pre[k] = *reinterpret_cast<const uint4*>(wt + ((long long)t * 64 + row) * CoutP + blk * WBLK + chunk * 8);
       }
     }
+    mpre = mrow[blk * WBLK];                       // (a wave past the volume reads block 0's: never used)
   };
   auto commit = [&](int blk, unsigned char* buf) {
 #pragma unroll
@@ -1183,8 +1184,8 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_mask_kernel(
     const int k = blk * WBLK + lane;
     float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < Cout) gq = *reinterpret_cast<const float4*>(g + ((long long)n * Cout + k) * 4);
-    reinterpret_cast<float2*>(buf + IMG)[wv * WBLK + lane] =
-        make_float2((gq.x + gq.y * cz + gq.z * cy) * sDh, gq.w * sDh);
+    reinterpret_cast<float4*>(buf + IMG)[wv * WBLK + lane] =
+        make_float4((gq.x + gq.y * cz + gq.z * cy) * sDh, gq.w * sDh, __uint_as_float(mpre), 0.f);
   };
   fetch(0);
   commit(0, hsm);
@@ -1193,18 +1194,16 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_mask_kernel(
     unsigned char* buf = hsm + (blk & 1) * BUF;
     if (blk + 1 < nblk) fetch(blk + 1);
     const unsigned char* sWt = buf;
-    const float2* sAB = reinterpret_cast<const float2*>(buf + IMG) + wv * WBLK;
+    const float4* sAB = reinterpret_cast<const float4*>(buf + IMG) + wv * WBLK;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {                  // 32-channel tile of the block
-      unsigned long long mk[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mk[r] = mp[(blk * WBLK + 32 * m) / 2 + r];   // (a wave past the volume: block 0's, unused)
       float dh[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float2 ab = sAB[32 * m + (r & 3) + 8 * (r >> 2) + 4 * lh];
-        const float gd = fmaf(ab.y, cx, ab.x);
-        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(dh[r]) : "v"(gd), "s"(mk[r]));
+        const float4 ab = sAB[32 * m + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        unsigned mk;                               // the lane's voxel: bit li of the channel's word -> 0 / ~0
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mk) : "v"(ab.z), "v"(li));
+        dh[r] = __uint_as_float(__float_as_uint(fmaf(ab.y, cx, ab.x)) & mk);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -1489,7 +1488,7 @@ static int head_bwd_bf(const float* dpts, const float* dpower, const float* feat
     const __bf16* wkp = wk + (size_t)T * pl.CoutP * 64;
     const __bf16* wt = wkp + (size_t)T * pl.CoutP * 64;
     if (dfeat && mask) {
-      const size_t lds = 2 * ((size_t)T * 64 * 128 + 8 * WBLK * 8);
+      const size_t lds = 2 * ((size_t)T * 64 * 128 + 8 * WBLK * 16);
       auto kern = Cin > 32 ? headcom_bwd_feat_mask_kernel<T, true> : headcom_bwd_feat_mask_kernel<T, false>;
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
