@@ -122,20 +122,21 @@ __device__ __forceinline__ kmh_f32x16 mfma16(kmh_bf16x8 a, kmh_bf16x8 b, kmh_f32
 template <int TERMS>
 __device__ __forceinline__ void split_pair(float r0, float r1, unsigned out[TERMS]) {
   if constexpr (TERMS == 2) {
-    // hi = (f16(r0), f16(r1)) in ONE v_cvt_pk_f16_f32; lo = f16(r - f32(hi)) as ONE v_fma_mix{lo,hi}_f16 per value: the
-    // instruction's operand selector converts the fp16 half of `hi` (op_sel_hi[0] = 1: source 0 is fp16, op_sel[0]: its
-    // high half), the fma is exact in fp32 (the residual of a rounding is representable) and the result is rounded once
-    // to fp16 into the low / high half of the destination -- 3 VALU per pair, no unpacking, no in-place operands.
+    // hi = (f16(r0), f16(r1)) in ONE v_cvt_pk_f16_f32; the residual r - f32(hi) as ONE v_fma_mix_f32 per value (its
+    // operand selector converts the fp16 half of `hi`: op_sel_hi[0] = 1 says source 0 is fp16, op_sel[0] picks the high
+    // half), exact in fp32; lo = ONE more packed conversion.  Four VALU of the 1.8 ns class per pair
+    // (tools/ubench/valu_rates.hip; v_fma_mix{lo,hi}_f16, which would fold the last conversion, cost 3.4 ns each).
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     typedef float f2_t __attribute__((ext_vector_type(2)));
     const f2_t f = {r0, r1};
     const h2_t h = __builtin_convertvector(f, h2_t);
     const unsigned hb = __builtin_bit_cast(unsigned, h);
     out[0] = hb;
-    unsigned lo;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hb), "v"(r0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hb), "v"(r1));
-    out[1] = lo;
+    float e0, e1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(e0) : "v"(hb), "v"(r0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(e1) : "v"(hb), "v"(r1));
+    const f2_t g = {e0, e1};
+    out[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(g, h2_t));
   } else {
 #pragma unroll
     for (int t = 0; t < TERMS; ++t) {
