@@ -1198,12 +1198,26 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_mask_kernel(
 #pragma unroll
     for (int m = 0; m < 2; ++m) {                  // 32-channel tile of the block
       float dh[16];
+      // the records in two batches of eight ds_read_b128, each batch issued before its first use: read by read (hipcc's
+      // placement) the wave parks at ~12 LDS round trips per tile and the kernel runs at that latency.  (The empty asm
+      // keeps each record one 128-bit read; the explicit v_fma keeps hipcc from packing pairs into v_pk_fma_f32 + moves.)
+      typedef float kmh_f4 __attribute__((ext_vector_type(4)));
+      const kmh_f4* sAB4 = reinterpret_cast<const kmh_f4*>(sAB);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float4 ab = sAB[32 * m + (r & 3) + 8 * (r >> 2) + 4 * lh];
-        unsigned mk;                               // the lane's voxel: bit li of the channel's word -> 0 / ~0
-        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mk) : "v"(ab.z), "v"(li));
-        dh[r] = __uint_as_float(__float_as_uint(fmaf(ab.y, cx, ab.x)) & mk);
+      for (int hb = 0; hb < 2; ++hb) {
+        kmh_f4 ab[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ab[r] = sAB4[32 * m + (r & 3) + 8 * ((8 * hb + r) >> 2) + 4 * lh];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          asm volatile("" : "+v"(ab[r]));
+          unsigned mk;                             // the lane's voxel: bit li of the channel's word -> 0 / ~0
+          float gd;
+          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mk) : "v"(ab[r].z), "v"(li));
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(gd) : "v"(ab[r].y), "v"(cx), "v"(ab[r].x));
+          dh[8 * hb + r] = __uint_as_float(__float_as_uint(gd) & mk);
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
