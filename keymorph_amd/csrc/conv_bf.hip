@@ -1239,11 +1239,13 @@ __global__ __launch_bounds__(DUP_TPB, 3) void conv3_up2_dgrad_kernel(
 // ---- weight gradient of the same operator: C_n (Cl x J) = A_n^T B_n over the low-resolution voxels, A = the normalised
 // low tensor (V x Cl), B = the box sums of dz (V x J, J = 27 Cout, norm.hip: up2_boxsum_kernel).  Both operands have the
 // reduction index slowest, so both are transposed while they are staged (voxel pairs packed into 32-bit LDS words, like
-// the 27-tap weight gradient's images).  Workgroup = 128 x 128 tile of C over one K slab, 64 voxels per step; wave = 64 x 64.
-constexpr int GK = 64;                        // voxels per staging step
-constexpr int GPITCH = GK * 2 + 16;           // bytes per LDS row (64 x 2 B + pad: 9 x 16 B, conflict-free b128 reads)
+// the 27-tap weight gradient's images).  Workgroup = 128 x 128 tile of C over one K slab, 32 voxels per step; wave = 64 x 64.
+// Bound: a CU streams in ~10 B / cycle (256 CUs: 5.1 TB/s), this tile loads (128 + 128) x 4 B per 2 x 128 x 128 multiply-adds.  A
+// 128 x 256 tile on 8 waves (1.33x the intensity) needs 176 registers = ONE workgroup per CU and is no faster (2.97 vs 2.86 ms).
+constexpr int GK = 32;                        // voxels per staging step (64: two workgroups per CU, 5 % slower)
+constexpr int GPITCH = GK * 2 + 16;           // bytes per LDS row (32 x 2 B + pad: 5 x 16 B, conflict-free b128 reads)
 template <int TERMS>
-__global__ __launch_bounds__(256, 2) void up2_wgrad_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
+__global__ __launch_bounds__(256, 3) void up2_wgrad_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                 float* __restrict__ Cp, int V, int Cl, int J, int kslab,
                                                                 int ntn, int ntm, const float* __restrict__ ascale,
                                                                 const float* __restrict__ bscale) {
@@ -1272,11 +1274,12 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_gemm_kernel(const float* __r
   int k_end = k_beg + kslab;
   if (k_end > V) k_end = V;
   // staging items: (voxel pair kp, column quad cq) -> 2 float4 loads, 4 packed words per term
-  float4 pa[4][2], pb[4][2];
+  constexpr int NKP = GK / 2, NIT = GK / 16;   // voxel pairs per step, staging items per thread
+  float4 pa[NIT][2], pb[NIT][2];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256, cq = (e & 3) + 4 * (e >> 7), kp = (e >> 2) & 31;   // lanes: 4 quads x 16 voxel pairs
+    for (int i = 0; i < NIT; ++i) {
+      const int e = tid + i * 256, cq = (e & 3) + 4 * (e / (4 * NKP)), kp = (e >> 2) & (NKP - 1);   // lanes: 4 quads x 16 voxel pairs
       const int k = k0 + 2 * kp;
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       const int ca = m0 + 4 * cq, cb = n0 + 4 * cq;
@@ -1288,8 +1291,8 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_gemm_kernel(const float* __r
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256, cq = (e & 3) + 4 * (e >> 7), kp = (e >> 2) & 31;   // (2-way LDS write conflicts at most)
+    for (int i = 0; i < NIT; ++i) {
+      const int e = tid + i * 256, cq = (e & 3) + 4 * (e / (4 * NKP)), kp = (e >> 2) & (NKP - 1);   // (2-way LDS write conflicts at most)
       const float a0[4] = {pa[i][0].x, pa[i][0].y, pa[i][0].z, pa[i][0].w}, a1[4] = {pa[i][1].x, pa[i][1].y, pa[i][1].z, pa[i][1].w};
       const float b0[4] = {pb[i][0].x, pb[i][0].y, pb[i][0].z, pb[i][0].w}, b1[4] = {pb[i][1].x, pb[i][1].y, pb[i][1].z, pb[i][1].w};
 #pragma unroll
