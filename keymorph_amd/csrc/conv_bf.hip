@@ -1126,12 +1126,13 @@ __global__ __launch_bounds__(256) void pack_weight_upt_kernel(const float* __res
 }
 
 template <int TERMS>
-__global__ __launch_bounds__(DUP_TPB, 3) void conv3_up2_dgrad_kernel(
+__global__ __launch_bounds__(DUP_TPB, TERMS == 2 ? 2 : 3) void conv3_up2_dgrad_kernel(
     const float* __restrict__ dz /* (N,2Dl,2Hl,2Wl,Cout) */, const bf16x8* __restrict__ wp,
     float* __restrict__ ds /* (N,Dl,Hl,Wl,Cl) */, int Dl, int Hl, int Wl, int Cl, int CiP, int Cout, int tiles_x,
     int tiles_y, const float* __restrict__ dscale, const float* __restrict__ wscale) {
   // Workgroup = 16 x 4 x 1 low voxels = two M tiles of (16 x, 2 y); wave = one 32-channel tile of ci, both M tiles.
-  // 43.5 KB of LDS and <= 170 registers: three workgroups per CU, whose staging and MFMA phases overlap.
+  // 43.5 KB of LDS; two (f16x3, prefetching: 224 registers) or three (bf16x6) workgroups per CU, whose staging and MFMA
+  // phases overlap.
   __shared__ bf16x8 sIn[TERMS][DPL];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int n = blockIdx.z;
@@ -1156,30 +1157,46 @@ __global__ __launch_bounds__(DUP_TPB, 3) void conv3_up2_dgrad_kernel(
   // row li of an M tile = low voxel (x = li & 15, y = 2 mt + (li >> 4)); its halo origin is (2 y, 2 x)
   const int abase = (2 * (li >> 4)) * DHX + 2 * (li & 15) + lh;
 
-  for (int ch = 0; ch < nchunk; ++ch) {
-    __syncthreads();                                    // the previous chunk's readers are done
+  // the next chunk's halo is fetched into registers under this chunk's MFMAs (staging it at the top of its own chunk left
+  // an HBM round trip exposed per chunk and workgroup)
+  float4 pre[NV][2];
+  auto fetch = [&](int ch) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = tid + i * DUP_TPB;
+      pre[i][0] = pre[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (v < DPL) {
         const int lx = v % DHX, ly = (v / DHX) % DHY, lz = v / (DHX * DHY);
         const int gx = 2 * x0 - 1 + lx, gy = 2 * y0 - 1 + ly, gz = 2 * zl - 1 + lz;
-        float val[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D) {
           const float* p = dn + (((long long)gz * H + gy) * W + gx) * Cout + ch * KC;
           if ((Cout & 3) == 0) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
-              if (ch * KC + 4 * q < Cout) {
-                const float4 t4 = *reinterpret_cast<const float4*>(p + 4 * q);
-                val[4 * q] = t4.x * sD; val[4 * q + 1] = t4.y * sD; val[4 * q + 2] = t4.z * sD; val[4 * q + 3] = t4.w * sD;
-              }
+              if (ch * KC + 4 * q < Cout) pre[i][q] = *reinterpret_cast<const float4*>(p + 4 * q);
           } else {
+            float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-              if (ch * KC + j < Cout) val[j] = p[j] * sD;
+              if (ch * KC + j < Cout) t8[j] = p[j];
+            pre[i][0] = make_float4(t8[0], t8[1], t8[2], t8[3]);
+            pre[i][1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
           }
         }
+      }
+    }
+  };
+  constexpr bool PF = TERMS == 2;                       // (the three-term variant has no registers to spare: it fetches in place)
+  if (PF) fetch(0);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    __syncthreads();                                    // the previous chunk's readers are done
+    if (!PF) fetch(ch);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * DUP_TPB;
+      if (v < DPL) {
+        const float val[8] = {pre[i][0].x * sD, pre[i][0].y * sD, pre[i][0].z * sD, pre[i][0].w * sD,
+                              pre[i][1].x * sD, pre[i][1].y * sD, pre[i][1].z * sD, pre[i][1].w * sD};
         bf16x8 parts[TERMS];
         split8<TERMS>(val, parts);
 #pragma unroll
@@ -1187,6 +1204,7 @@ __global__ __launch_bounds__(DUP_TPB, 3) void conv3_up2_dgrad_kernel(
       }
     }
     __syncthreads();
+    if (PF && ch + 1 < nchunk) fetch(ch + 1);
     const bf16x8* wc = wp + (long long)ch * TERMS * DUP_NST * 2 * CiP + lh * CiP + ci;
     constexpr int BD = 4;
     bf16x8 bq[BD][TERMS];
