@@ -51,6 +51,35 @@ def rescale_intensity(array, out_range=(0, 1), percentiles=(0, 100)):
 _MAX_LABEL = 1 << 16     # label ids handled by the presence bitmap (FreeSurfer / BrainMorph label maps are < 2^16)
 
 
+
+def sample_valid_coordinates(x, num_points, dim, point_space="norm", indexing="xy"):
+    """`num_points` random foreground voxels of x (1,1,H,W) / (1,1,D,H,W) as (1, num_points, dim) coordinates -- what
+    scripts/run.py:528-548 draws as pre-training reference keypoints (keymorph/utils.py:97-162).  Same draws from numpy's
+    global generator as the reference (one np.random.randint per axis and attempt, slowest axis first; accepted when the
+    voxel is foreground: > 0 in 2-D, > 0.1 in 3-D), same outputs: "norm" -> index / size per axis as float32, anything
+    else -> the integer indices (int64); fastest axis first ("xy"), reversed for indexing == "ij".  The volume is read
+    on the host once instead of building a one-hot volume per attempt."""
+    import numpy as np
+    if dim not in (2, 3):
+        raise NotImplementedError
+    if x.dim() != dim + 2 or x.shape[0] != 1 or x.shape[1] != 1:
+        raise ValueError(f"sample_valid_coordinates expects a (1, 1, ...) volume with {dim} spatial axes, got {tuple(x.shape)}")
+    sizes = [int(n) for n in x.shape[2:]]
+    fg = (x[0, 0] > (0 if dim == 2 else 1e-1)).cpu().numpy()
+    if not fg.any():
+        raise ValueError("sample_valid_coordinates: the volume has no foreground voxel to sample")
+    rows = []
+    for _ in range(num_points):
+        while True:
+            idx = tuple(int(np.random.randint(0, n)) for n in sizes)
+            if fg[idx]:
+                break
+        rev = idx[::-1]
+        rows.append([i / n for i, n in zip(rev, sizes[::-1])] if point_space == "norm" else list(rev))
+    coords = torch.tensor(rows).view(1, num_points, dim)
+    return coords.flip(-1) if indexing == "ij" else coords
+
+
 def _seg_on_gpu(seg):
     """The reference's loops call the encoders on the loader's CPU tensors and move the result to the device
     afterwards (scripts/train.py:54-79); here the label map goes to the current GPU first and the encoding is

@@ -329,3 +329,28 @@ def test_flat_params_gathers_gradients():
     flat.zero_grad()
     loss().backward()
     assert torch.allclose(flat.grad[:params[0].numel()].view_as(params[0]), ref[0])
+
+
+def test_sample_valid_coordinates_golden():
+    """keymorph/utils.py:97-162 (scripts/run.py:528-548 draws pre-training keypoints with it): the same points as the
+    reference for the same numpy seed, the same dtype, and the global generator left in the same state."""
+    from keymorph_amd.utils import sample_valid_coordinates
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "valid_coords_small.npz"))
+    x3, x2 = torch.tensor(d["x3"]), torch.tensor(d["x2"])
+    for tag, x, dim, space, indexing in (("a", x3, 3, "norm", "xy"), ("b", x3, 3, "norm", "ij"), ("c", x3, 3, "voxel", "xy"),
+                                         ("d", x2, 2, "norm", "xy"), ("e", x2, 2, "voxel", "ij")):
+        np.random.seed(int(d[f"{tag}::seed"][0]))
+        pts = sample_valid_coordinates(x, 6, dim, point_space=space, indexing=indexing)
+        assert str(pts.dtype) == str(d[f"{tag}::dtype"]) and tuple(pts.shape) == (1, 6, dim)
+        np.testing.assert_array_equal(pts.numpy().astype(np.float64), d[f"{tag}::points"])
+        assert int(np.random.randint(0, 1 << 30)) == int(d[f"{tag}::after"][0])
+        # every point is a foreground voxel of x
+        p = pts.flip(-1) if indexing == "xy" else pts                         # -> slowest axis first
+        sizes = torch.tensor(x.shape[2:], dtype=torch.float64)
+        idx = (p[0].double() * sizes).round().long() if space == "norm" else p[0].long()
+        vals = x[0, 0][tuple(idx[:, k] for k in range(dim))]
+        assert bool((vals > (0 if dim == 2 else 0.1)).all())
+    with pytest.raises(NotImplementedError):
+        sample_valid_coordinates(x3, 2, 4)
+    with pytest.raises(ValueError):
+        sample_valid_coordinates(torch.zeros(1, 1, 3, 3, 3), 2, 3)

@@ -840,13 +840,37 @@ def gen_groupwise_eval():
     print("groupwise_eval_tiny.npz", len(d), "arrays")
 
 
+def gen_valid_coords():
+    """keymorph/utils.py:97-162: sample_valid_coordinates (rejection sampling with np.random.randint draws; used by
+    scripts/run.py:528-548 to draw the pre-training reference keypoints)."""
+    import contextlib, io
+    from keymorph.utils import sample_valid_coordinates
+    g = torch.Generator().manual_seed(41)
+    d = {}
+    x3 = torch.rand(1, 1, 7, 9, 11, generator=g) * (torch.rand(1, 1, 7, 9, 11, generator=g) > 0.6)
+    x2 = torch.rand(1, 1, 8, 13, generator=g) * (torch.rand(1, 1, 8, 13, generator=g) > 0.5)
+    d["x3"], d["x2"] = npy(x3), npy(x2)
+    for tag, x, dim, seed, space, indexing in (("a", x3, 3, 5, "norm", "xy"), ("b", x3, 3, 6, "norm", "ij"),
+                                               ("c", x3, 3, 7, "voxel", "xy"), ("d", x2, 2, 8, "norm", "xy"),
+                                               ("e", x2, 2, 9, "voxel", "ij")):
+        np.random.seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):            # the reference prints a progress line per point
+            pts = sample_valid_coordinates(x, 6, dim, point_space=space, indexing=indexing)
+        d[f"{tag}::seed"] = np.asarray([seed])
+        d[f"{tag}::points"] = np.asarray(pts.numpy(), dtype=np.float64)
+        d[f"{tag}::dtype"] = np.asarray(str(pts.dtype))
+        d[f"{tag}::after"] = np.asarray([np.random.randint(0, 1 << 30)])   # the generator state the caller is left with
+    np.savez_compressed(os.path.join(OUT, "valid_coords_small.npz"), **d)
+    print("valid_coords_small.npz", len(d), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = {"ops": gen_ops, "backbones": gen_backbones, "e2e": gen_e2e, "groupwise": gen_groupwise,
             "tps_illcond": gen_tps_illcond, "augment": gen_augment, "weighted": gen_weighted,
             "groupwise_truth": gen_groupwise_truth, "realworld": gen_realworld, "onehot": gen_onehot,
             "gradients": gen_gradients, "weighted_subsample": gen_weighted_subsample, "trainstep": gen_trainstep,
-            "cfg1": gen_cfg1, "groupwise_eval": gen_groupwise_eval}
+            "cfg1": gen_cfg1, "groupwise_eval": gen_groupwise_eval, "valid_coords": gen_valid_coords}
     for name in (sys.argv[1:] or list(gens)):      # e.g. `make_golden.py augment` regenerates one fixture
         torch.manual_seed(0)
         np.random.seed(0)
