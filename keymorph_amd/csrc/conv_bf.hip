@@ -2415,42 +2415,47 @@ __global__ __launch_bounds__(256) void wgrad_bf_reduce_kernel(const float* __res
 //   bhat[n][ci] = sum_{tap, co} w[co][ci][tap] * dWn[n][tap][ci][co]  =  sum_v dxn[n][v][ci] * xhat[n][v][ci]
 // (dxn = the data gradient of the same dz, xhat = the convolution's input): GroupNorm's second backward statistic
 // without a pass over dxn and x.  Block = (ci, tap triple); bhat must be zero on entry.
-__global__ __launch_bounds__(256) void wgrad_bf_reduce_fold_kernel(const float* __restrict__ partial, int N, int per_n,
-                                                                   int Cin, int Cout, float* __restrict__ dw,
-                                                                   int accumulate, const float* __restrict__ xscale,
-                                                                   const float* __restrict__ dscale,
-                                                                   const float* __restrict__ w,
-                                                                   double* __restrict__ bhat) {
+// 1024 threads = LP columns (the next power of two >= 3 Cout, capped at 1024) x S = 1024 / LP slices of the slabs: the
+// slab sums are strided reads 27 Cin Cout floats apart, and one thread walking all of them ran at 1.1 TB/s.
+__global__ __launch_bounds__(1024) void wgrad_bf_reduce_fold_kernel(const float* __restrict__ partial, int N, int per_n,
+                                                                    int Cin, int Cout, float* __restrict__ dw,
+                                                                    int accumulate, const float* __restrict__ xscale,
+                                                                    const float* __restrict__ dscale,
+                                                                    const float* __restrict__ w,
+                                                                    double* __restrict__ bhat, int LP) {
   const double desc = (double)(xscale ? xscale[1] : 1.f) * (double)(dscale ? dscale[1] : 1.f);
   const long long total = (long long)27 * Cin * Cout;
   const int ci = blockIdx.x, t3 = blockIdx.y;
-  __shared__ double red[256 / kWave];
-  constexpr int NMAX = 8;
-  for (int n0 = 0; n0 < N; n0 += NMAX) {
-    double b[NMAX];
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j) b[j] = 0;
-    for (int l = threadIdx.x; l < 3 * Cout; l += 256) {
-      const int tap = 3 * t3 + l / Cout, co = l % Cout;
-      const long long e = ((long long)tap * Cin + ci) * Cout + co;
-      const long long o = ((long long)co * Cin + ci) * 27 + tap;
-      const double wv = (double)w[o];
-      double tot = 0;
-      for (int n = 0; n < N; ++n) {
-        double sn = 0;
-        for (int k = 0; k < per_n; ++k) sn += partial[((long long)n * per_n + k) * total + e];
+  __shared__ double red[1024];
+  __shared__ double wred[1024 / kWave];
+  const int S = 1024 / LP, lcol = threadIdx.x % LP, sl = threadIdx.x / LP;
+  const int L = 3 * Cout;
+  for (int l0 = 0; l0 < L; l0 += LP) {                      // (one pass unless 3 Cout > 1024)
+    const int l = l0 + lcol;
+    const bool act = l < L;
+    const int tap = 3 * t3 + (act ? l / Cout : 0), co = act ? l % Cout : 0;
+    const long long e = ((long long)tap * Cin + ci) * Cout + co;
+    const long long o = ((long long)co * Cin + ci) * 27 + tap;
+    const double wv = act ? (double)w[o] : 0.0;
+    double tot = 0;
+    for (int n = 0; n < N; ++n) {
+      double sn = 0;
+      if (act)
+        for (int k = sl; k < per_n; k += S) sn += partial[((long long)n * per_n + k) * total + e];
+      __syncthreads();
+      red[threadIdx.x] = sn;
+      __syncthreads();
+      double bn = 0;
+      if (sl == 0 && act) {
+        sn = 0;
+        for (int q = 0; q < S; ++q) sn += red[q * LP + lcol];      // fixed order
         tot += sn;
-        if (n >= n0 && n < n0 + NMAX) b[n - n0] += wv * sn * desc;
+        bn = wv * sn * desc;
       }
-      if (n0 == 0) dw[o] = accumulate ? dw[o] + (float)(tot * desc) : (float)(tot * desc);
+      const double r = block_sum<double>(bn, wred);
+      if (threadIdx.x == 0) atomicAdd(bhat + (long long)n * Cin + ci, r);
     }
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j) {
-      if (n0 + j < N) {                                   // uniform
-        const double r = block_sum<double>(b[j], red);
-        if (threadIdx.x == 0) atomicAdd(bhat + (long long)(n0 + j) * Cin + ci, r);
-      }
-    }
+    if (sl == 0 && act) dw[o] = accumulate ? dw[o] + (float)(tot * desc) : (float)(tot * desc);
   }
 }
 
@@ -2574,8 +2579,12 @@ KMH_API int kmh_conv3d_wgrad_bf(const float* x, const float* scale, const float*
   int nb = ceil_div(total, 256);
   if (nb > 2048) nb = 2048;
   if (bhat)
-    wgrad_bf_reduce_fold_kernel<<<dim3(Cin, 9), 256, 0, s>>>((const float*)ws, N, (p.nslab / N) * p.KS, Cin, Cout, dw,
-                                                             accumulate, xscale, dscale, w_fold, bhat);
+  {
+    int LP = 64;
+    while (LP < 3 * Cout && LP < 1024) LP <<= 1;
+    wgrad_bf_reduce_fold_kernel<<<dim3(Cin, 9), 1024, 0, s>>>((const float*)ws, N, (p.nslab / N) * p.KS, Cin, Cout, dw,
+                                                              accumulate, xscale, dscale, w_fold, bhat, LP);
+  }
   else
     wgrad_bf_reduce_kernel<<<nb, 256, 0, s>>>((const float*)ws, p.nslab * p.KS, Cin, Cout, dw, accumulate, xscale, dscale);
   return KMH_LAUNCH_CHECK();

@@ -89,12 +89,19 @@ __global__ __launch_bounds__(TPB) void affine_grid_bwd_partial(const float* __re
   }
 }
 
-__global__ void affine_grid_bwd_final(const double* __restrict__ partial, int nblk, float* __restrict__ dmat) {
+// 12 outputs x 16 slices of the per-block partials, combined in a fixed order (12 threads walking 1024 partials: 0.2 ms)
+__global__ __launch_bounds__(192) void affine_grid_bwd_final(const double* __restrict__ partial, int nblk, float* __restrict__ dmat) {
+  __shared__ double red[16][12];
   const int n = blockIdx.x;
-  const int i = threadIdx.x;  // 0..11
-  if (i >= 12) return;
+  const int i = threadIdx.x % 12, sl = threadIdx.x / 12;   // 192 threads
   double s = 0;
-  for (int b = 0; b < nblk; ++b) s += partial[((long long)n * nblk + b) * 12 + i];
+  for (int b = sl; b < nblk; b += 16) s += partial[((long long)n * nblk + b) * 12 + i];
+  red[sl][i] = s;
+  __syncthreads();
+  if (sl) return;
+  s = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += red[k][i];
   dmat[n * 12 + i] = (float)s;
 }
 
@@ -435,7 +442,7 @@ KMH_API int kmh_affine_grid_bwd(const float* dgrid, float* dmat, int N, int D, i
   if ((size_t)N * nb * 12 * sizeof(double) > (size_t)65536 * 8 * 3) return -22;
   hipStream_t s = (hipStream_t)stream;
   affine_grid_bwd_partial<<<dim3(nb, N), TPB, 0, s>>>(dgrid, (double*)ws, D, H, W);
-  affine_grid_bwd_final<<<N, 64, 0, s>>>((const double*)ws, nb, dmat);
+  affine_grid_bwd_final<<<N, 192, 0, s>>>((const double*)ws, nb, dmat);
   return KMH_LAUNCH_CHECK();
 }
 
@@ -485,7 +492,7 @@ KMH_API int kmh_tps_grid_bwd(const float* dgrid, const float* theta, const float
   tps_bwd_final_kernel<<<dim3(ceil_div(T * 6, FIN_O), N), FIN_O * FIN_S, 0, s>>>(partial, nchunk, T, dtheta, dctrl, 0);
   const int nb = affine_bwd_blocks(nvox);
   affine_grid_bwd_partial<<<dim3(nb, N), TPB, 0, s>>>(dgrid, affp, D, H, W);
-  affine_grid_bwd_final<<<N, 64, 0, s>>>(affp, nb, dmat);
+  affine_grid_bwd_final<<<N, 192, 0, s>>>(affp, nb, dmat);
   tps_affine_rows_kernel<<<N, 64, 0, s>>>(dmat, T, dtheta);
   return KMH_LAUNCH_CHECK();
 }

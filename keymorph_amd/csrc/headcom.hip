@@ -331,12 +331,20 @@ __global__ __launch_bounds__(HTPB, 2) void headcom_bwd_w_kernel(const float* __r
   }
 }
 
+// out[e] = sum over the per-slab partials, fp64, fixed order: 64 outputs x 4 slices of the slabs per workgroup
 __global__ __launch_bounds__(256) void headcom_reduce_kernel(const float* __restrict__ partial, int nparts,
                                                              long long total, float* __restrict__ out) {
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+  __shared__ double red[4][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  for (long long e0 = (long long)blockIdx.x * 64; e0 < total; e0 += (long long)gridDim.x * 64) {
+    const long long e = e0 + o;
     double s = 0;
-    for (int k = 0; k < nparts; ++k) s += partial[(long long)k * total + e];
-    out[e] = (float)s;
+    if (e < total)
+      for (int k = sl; k < nparts; k += 4) s += partial[(long long)k * total + e];
+    __syncthreads();
+    red[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && e < total) out[e] = (float)((red[0][o] + red[1][o]) + (red[2][o] + red[3][o]));
   }
 }
 
@@ -1323,10 +1331,10 @@ KMH_API int kmh_headcom_bwd(const float* dpts, const float* dpower, const float*
   if (dw) {
     headcom_bwd_w_kernel<<<dim3(ns, ceil_div(Cout, GC)), HTPB, 0, s>>>(feat, w, bias, g, pw, pb, N, V, Cin, Cout, d,
                                                                       tps);
-    int nb = ceil_div((long long)Cout * Cin, 256);
-    if (nb > 1024) nb = 1024;
+    int nb = ceil_div((long long)Cout * Cin, 64);
+    if (nb > 2048) nb = 2048;
     headcom_reduce_kernel<<<nb, 256, 0, s>>>(pw, ns * 4, (long long)Cout * Cin, dw);
-    if (dbias) headcom_reduce_kernel<<<ceil_div(Cout, 256), 256, 0, s>>>(pb, ns * 4, Cout, dbias);
+    if (dbias) headcom_reduce_kernel<<<ceil_div(Cout, 64), 256, 0, s>>>(pb, ns * 4, Cout, dbias);
   }
   return KMH_LAUNCH_CHECK();
 }
@@ -1549,10 +1557,10 @@ static int head_bwd_bf(const float* dpts, const float* dpower, const float* feat
   }
   if (dfeat && dfeat_scale2) kmh_absmax::final_kernel<<<1, 1, 0, s>>>(dfeat_scale2, 0.f);
   if (dw) {
-    int nb = ceil_div((long long)Cout * Cin, 256);
-    if (nb > 1024) nb = 1024;
+    int nb = ceil_div((long long)Cout * Cin, 64);
+    if (nb > 2048) nb = 2048;
     headcom_reduce_kernel<<<nb, 256, 0, s>>>(pw, p.nslab_w, (long long)Cout * Cin, dw);
-    if (dbias) headcom_reduce_kernel<<<ceil_div(Cout, 256), 256, 0, s>>>(pb, p.nslab_w, Cout, dbias);
+    if (dbias) headcom_reduce_kernel<<<ceil_div(Cout, 64), 256, 0, s>>>(pb, p.nslab_w, Cout, dbias);
   }
   return KMH_LAUNCH_CHECK();
 }
