@@ -204,8 +204,12 @@ int kmh_conv3d_up2_pack_weight(const float* w, void* packed, int Cout, int Ctot,
 size_t kmh_conv3d_up2_dgrad_pack_bytes(int Cout, int Cl, int terms);
 int kmh_conv3d_up2_dgrad_pack_weight(const float* w, void* packed, int Cout, int Ctot, int cofs, int Cl, int terms,
                                      const float* wscale, void* stream);
+/* stats_out (N,Cl,2) doubles | NULL: per-channel (sum ds, sum ds^2) from the epilogue (what GroupNorm's backward of the
+ * decoder block needs from this gradient: no separate pass over ds); stats_ws: ..._stats_ws_bytes (may be NULL with it) */
+size_t kmh_conv3d_up2_dgrad_stats_ws_bytes(int N, int Dl, int Hl, int Wl, int Cl);
 int kmh_conv3d_up2_dgrad(const float* dz, const void* packed, float* ds, int N, int Dl, int Hl, int Wl, int Cl, int Cout,
-                         int terms, const float* dscale, const float* wscale, void* stream);
+                         int terms, const float* dscale, const float* wscale, void* stats_ws, double* stats_out,
+                         void* stream);
 /* weight gradient of the same operator (csrc/norm.hip): G (N, Dl*Hl*Wl, 27, Cout) = 2x2x2 box sums of dz such that
  * dW[tap][ci][co] = sum_m x_low[m][ci] G[m][tap][co] -- one plain matrix product over the low-resolution voxels */
 int kmh_up2_boxsum(const float* dz, float* G, int N, int Dl, int Hl, int Wl, int Cout, void* stream);

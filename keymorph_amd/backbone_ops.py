@@ -299,7 +299,8 @@ def first_layer_grads(x, scale, shift, mr, gamma, weight, dy, ymask, N, D, H, W,
     return dw, dgamma, dbeta
 
 
-def conv3_up2_dgrad(dz: Tensor, weight: Tensor, Cs: int, Cl: int, dscale: Optional[Tensor] = None) -> Tensor:
+def conv3_up2_dgrad(dz: Tensor, weight: Tensor, Cs: int, Cl: int, dscale: Optional[Tensor] = None,
+                    stats_out: Optional[Tensor] = None) -> Tensor:
     """dz (N,D,H,W,Cout), weight (Cout, Cs+Cl, 3,3,3) -> (N,D/2,H/2,W/2,Cl): for every low voxel the sum over its 8
     children of the data gradient with respect to the nearest-x2 upsampled channels [Cs, Cs+Cl) -- computed at low
     resolution with 64 pre-summed taps (csrc/conv_bf.hip: conv3_up2_dgrad)."""
@@ -317,8 +318,12 @@ def conv3_up2_dgrad(dz: Tensor, weight: Tensor, Cs: int, Cl: int, dscale: Option
     ds = _f32((N, D // 2, H // 2, W // 2, Cl), dz.device)
     if _lib.profiler.enabled:
         _lib.profiler.meta = {"flops": 2.0 * 8 * Cl * Cout * N * D * H * W, "shape": (N, D, H, W, Cout, Cl)}
+    sws = None
+    if stats_out is not None:        # (N, Cl, 2) float64: per-channel (sum, sum of squares) of ds, from the epilogue
+        sws = workspace(int(lib.kmh_conv3d_up2_dgrad_stats_ws_bytes(N, D // 2, H // 2, W // 2, Cl)), dz.device, "convstats")
     check(lib.kmh_conv3d_up2_dgrad(_p(dz), _p(pk), _p(ds), N, D // 2, H // 2, W // 2, Cl, Cout, terms,
-                                   _p(dscale if terms == 2 else None), _p(wsu), _stream()), "kmh_conv3d_up2_dgrad")
+                                   _p(dscale if terms == 2 else None), _p(wsu), _p(sws), _p(stats_out), _stream()),
+          "kmh_conv3d_up2_dgrad")
     return ds
 
 
@@ -644,8 +649,8 @@ class _UpCatConvGCR(torch.autograd.Function):
         dst_s = torch.empty((N, Cs, 2), dtype=torch.float64, device=dy.device)
         dxn_s = conv3_raw(dy, None, None, pack_weight(weight[:, :Cs].contiguous(), True), None, N, D, H, W, Cout, Cs,
                           False, False, ascale=dscale, stats_out=dst_s)
-        dsum_l = conv3_up2_dgrad(dy, weight, Cs, Cl, dscale)
-        dst_l = channel_stats(dsum_l, None, N, V // 8, Cl)
+        dst_l = torch.empty((N, Cl, 2), dtype=torch.float64, device=dy.device)
+        dsum_l = conv3_up2_dgrad(dy, weight, Cs, Cl, dscale, stats_out=dst_l)
         dstats = torch.cat([dst_s, dst_l], dim=1)
         c123 = _f32((N, C, 3), dy.device)
         dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)

@@ -1129,7 +1129,8 @@ template <int TERMS>
 __global__ __launch_bounds__(DUP_TPB, TERMS == 2 ? 2 : 3) void conv3_up2_dgrad_kernel(
     const float* __restrict__ dz /* (N,2Dl,2Hl,2Wl,Cout) */, const bf16x8* __restrict__ wp,
     float* __restrict__ ds /* (N,Dl,Hl,Wl,Cl) */, int Dl, int Hl, int Wl, int Cl, int CiP, int Cout, int tiles_x,
-    int tiles_y, const float* __restrict__ dscale, const float* __restrict__ wscale) {
+    int tiles_y, const float* __restrict__ dscale, const float* __restrict__ wscale,
+    double* __restrict__ stats_partial /* (N, bricks, Cl, 2) | NULL: per-brick (sum ds, sum ds^2) of every channel */) {
   // Workgroup = 16 x 4 x 1 low voxels = two M tiles of (16 x, 2 y); wave = one 32-channel tile of ci, both M tiles.
   // 43.5 KB of LDS; two (f16x3, prefetching: 224 registers) or three (bf16x6) workgroups per CU, whose staging and MFMA
   // phases overlap.
@@ -1243,13 +1244,28 @@ __global__ __launch_bounds__(DUP_TPB, TERMS == 2 ? 2 : 3) void conv3_up2_dgrad_k
     }
   }
   if (ci >= Cl) return;
+  float s1 = 0.f, s2 = 0.f;                             // <= 32 values per lane: fp32, then fp64 per brick
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;  // row of the M tile
       const int gx = x0 + (row & 15), gy = y0 + 2 * m + (row >> 4);
-      if (gx < Wl && gy < Hl) ds[((((long long)n * Dl + zl) * Hl + gy) * Wl + gx) * Cl + ci] = acc[m][r] * desc;
+      if (gx < Wl && gy < Hl) {
+        const float v = acc[m][r] * desc;
+        ds[((((long long)n * Dl + zl) * Hl + gy) * Wl + gx) * Cl + ci] = v;
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+      }
+    }
+  }
+  if (stats_partial) {                                  // the consumer's GroupNorm backward wants sum ds per channel
+    double d1 = (double)s1, d2 = (double)s2;
+    d1 += __shfl_xor(d1, 32, 64);
+    d2 += __shfl_xor(d2, 32, 64);
+    if (lh == 0) {
+      double* o = stats_partial + (((long long)n * gridDim.x / ncig + brick) * Cl + ci) * 2;
+      o[0] = d1; o[1] = d2;
     }
   }
 }
@@ -1439,17 +1455,25 @@ KMH_API int kmh_conv3d_up2_dgrad_pack_weight(const float* w, void* packed, int C
 
 /* ds (N,Dl,Hl,Wl,Cl) = for every low voxel, the sum over its 8 children of the gradient of conv3(up2(.), w[:, cofs:cofs+Cl])
  * with respect to the upsampled tensor, from dz (N,2Dl,2Hl,2Wl,Cout) (no ReLU mask operand: dz is already masked). */
+KMH_API size_t kmh_conv3d_up2_dgrad_stats_ws_bytes(int N, int Dl, int Hl, int Wl, int Cl) {
+  return (size_t)N * ceil_div(Wl, DUX) * ceil_div(Hl, DUY) * Dl * Cl * 2 * sizeof(double);
+}
+/* stats_out (N,Cl,2) doubles | NULL (then stats_ws may be NULL): per-channel (sum ds, sum ds^2), from the epilogue */
 KMH_API int kmh_conv3d_up2_dgrad(const float* dz, const void* packed, float* ds, int N, int Dl, int Hl, int Wl, int Cl,
-                                 int Cout, int terms, const float* dscale, const float* wscale, void* stream) {
-  if ((terms != 2 && terms != 3) || (terms == 2 && (!dscale || !wscale))) return -22;
+                                 int Cout, int terms, const float* dscale, const float* wscale, void* stats_ws,
+                                 double* stats_out, void* stream) {
+  if ((terms != 2 && terms != 3) || (terms == 2 && (!dscale || !wscale)) || (stats_out && !stats_ws)) return -22;
   const int CiP = (Cl + 127) & ~127;
   const int tx = ceil_div(Wl, DUX), ty = ceil_div(Hl, DUY);
   dim3 g(tx * ty * Dl * ceil_div(Cl, 128), 1, N);
   hipStream_t s = (hipStream_t)stream;
+  double* sp = stats_out ? (double*)stats_ws : nullptr;
   if (terms == 2)
-    conv3_up2_dgrad_kernel<2><<<g, DUP_TPB, 0, s>>>(dz, (const bf16x8*)packed, ds, Dl, Hl, Wl, Cl, CiP, Cout, tx, ty, dscale, wscale);
+    conv3_up2_dgrad_kernel<2><<<g, DUP_TPB, 0, s>>>(dz, (const bf16x8*)packed, ds, Dl, Hl, Wl, Cl, CiP, Cout, tx, ty, dscale, wscale, sp);
   else
-    conv3_up2_dgrad_kernel<3><<<g, DUP_TPB, 0, s>>>(dz, (const bf16x8*)packed, ds, Dl, Hl, Wl, Cl, CiP, Cout, tx, ty, dscale, wscale);
+    conv3_up2_dgrad_kernel<3><<<g, DUP_TPB, 0, s>>>(dz, (const bf16x8*)packed, ds, Dl, Hl, Wl, Cl, CiP, Cout, tx, ty, dscale, wscale, sp);
+  if (stats_out)
+    kmh_stats::final_kernel<<<dim3(ceil_div(Cl * 2, 256 / kWave), N), 256, 0, s>>>(sp, tx * ty * Dl, Cl, stats_out);
   return KMH_LAUNCH_CHECK();
 }
 

@@ -700,10 +700,17 @@ def test_up2_data_gradient_at_low_resolution(cfg, mode):
         g = gen(41)
         dz = torch.randn(N, *dims, Cout, generator=g).to(DEV)
         w = (torch.randn(Cout, Cs + Cl, 3, 3, 3, generator=g) / np.sqrt(27 * Cout)).to(DEV)
-        got = B.conv3_up2_dgrad(dz, w, Cs, Cl)
+        st = torch.full((N, Cl, 2), float("nan"), dtype=torch.float64, device=DEV)
+        got = B.conv3_up2_dgrad(dz, w, Cs, Cl, stats_out=st)
         full = F.conv_transpose3d(ncdhw(dz).double().cpu(), w.double().cpu(), padding=1)[:, Cs:]     # (N,Cl,D,H,W)
         ref = full.reshape(N, Cl, ld[0], 2, ld[1], 2, ld[2], 2).sum(dim=(3, 5, 7))
         close(ncdhw(got).double(), ref, 3e-6 * float(ref.abs().max()), 1e-4)
+        # epilogue statistics (what the decoder block's GroupNorm backward reads instead of a pass over the gradient):
+        # per-channel (sum, sum of squares) of exactly the values written
+        gd = got.double().reshape(N, -1, Cl)
+        want = torch.stack([gd.sum(1), (gd * gd).sum(1)], dim=-1)
+        close(st, want, 1e-6 * float(want.abs().max()), 1e-6)
+        assert torch.equal(got, B.conv3_up2_dgrad(dz, w, Cs, Cl))            # and the gradient itself does not depend on them
     finally:
         B.set_conv_mode(old)
 
