@@ -214,10 +214,14 @@ int kmh_conv3d_up2_dgrad(const float* dz, const void* packed, float* ds, int N, 
  * dW[tap][ci][co] = sum_m x_low[m][ci] G[m][tap][co] -- one plain matrix product over the low-resolution voxels */
 int kmh_up2_boxsum(const float* dz, float* G, int N, int Dl, int Hl, int Wl, int Cout, void* stream);
 /* C (N, Cl, J) = A^T B per sample over the V low-resolution voxels: A (N, V, Cl) the normalised low tensor, B (N, V, J)
- * the box sums with J = 27 Cout (split-operand MFMA; ascale / bscale = {S, 1/S} of A and B for terms == 2) */
+ * the box sums with J = 27 Cout (split-operand MFMA; ascale / bscale = {S, 1/S} of A and B for terms == 2).
+ * a_scale / a_shift (N, Cl) | both NULL: A is the RAW low tensor and GroupNorm's affine a_scale[n][c] A + a_shift[n][c]
+ * (keymorph/unet3d/buildingblocks.py:46-78, "g" of "gcr") is applied while it is staged; ascale is then the range scale
+ * of the normalised values */
 size_t kmh_up2_wgrad_gemm_ws_bytes(int N, int V, int Cl, int J);
 int kmh_up2_wgrad_gemm(const float* A, const float* B, float* C, int N, int V, int Cl, int J, int terms,
-                       const float* ascale, const float* bscale, void* ws, void* stream);
+                       const float* ascale, const float* bscale, const float* a_scale, const float* a_shift, void* ws,
+                       void* stream);
 int kmh_conv3d_up2_fwd(const float* xl, const float* scale, const float* shift, int Ctot, int cofs, const void* packed,
                        float* y, int N, int Dl, int Hl, int Wl, int Cl, int Cout, int terms, const float* ascale,
                        const float* wscale, void* stream);

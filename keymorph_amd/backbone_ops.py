@@ -619,19 +619,18 @@ class _UpCatConvGCR(torch.autograd.Function):
             Vl = V // 8
             boxes = _f32((N, Vl, 27 * Cout), dy.device)
             check(lib.kmh_up2_boxsum(_p(dy), _p(boxes), N, D // 2, H // 2, W // 2, Cout, _stream()), "kmh_up2_boxsum")
-            xl = torch.empty_like(low)
             sc_l, sh_l = scale[:, Cs:].contiguous(), shift[:, Cs:].contiguous()   # named: they must outlive the launch
-            check(lib.kmh_norm_apply(_p(low), _p(sc_l), _p(sh_l), N, Vl, Cl, 0, _p(xl), _stream()), "kmh_norm_apply")
             terms = _TERMS[CONV_MODE]
             dwn = _f32((N, Cl, 27, Cout), dy.device)
             gws = workspace(int(lib.kmh_up2_wgrad_gemm_ws_bytes(N, Vl, Cl, 27 * Cout)), dy.device, "wgrad")
             bsc = (dscale * torch.tensor([0.125, 8.0], device=dy.device)) if terms == 2 else None   # sums of 8
             if _lib.profiler.enabled:
                 _lib.profiler.meta = {"flops": 2.0 * 27 * Cl * Cout * N * Vl, "shape": (N, Vl, Cl, 27 * Cout)}
-            check(lib.kmh_up2_wgrad_gemm(_p(xl), _p(boxes), _p(dwn), N, Vl, Cl, 27 * Cout, terms,
-                                         _p(ctx.ascale if terms == 2 else None), _p(bsc), _p(gws), _stream()),
-                  "kmh_up2_wgrad_gemm")
-            del boxes, xl
+            # (the raw low tensor: GroupNorm's affine is applied while the product stages it)
+            check(lib.kmh_up2_wgrad_gemm(_p(low), _p(boxes), _p(dwn), N, Vl, Cl, 27 * Cout, terms,
+                                         _p(ctx.ascale if terms == 2 else None), _p(bsc), _p(sc_l), _p(sh_l), _p(gws),
+                                         _stream()), "kmh_up2_wgrad_gemm")
+            del boxes
             dw_l = dwn.sum(0).permute(2, 0, 1).reshape(Cout, Cl, 3, 3, 3)
             wl = weight[:, Cs:].reshape(Cout, Cl, 27).permute(1, 2, 0)                         # (Cl, 27, Cout)
             bhat_l = (dwn.double() * wl.double().unsqueeze(0)).sum(dim=(2, 3))

@@ -1282,7 +1282,9 @@ template <int TERMS>
 __global__ __launch_bounds__(256, 3) void up2_wgrad_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                 float* __restrict__ Cp, int V, int Cl, int J, int kslab,
                                                                 int ntn, int ntm, const float* __restrict__ ascale,
-                                                                const float* __restrict__ bscale) {
+                                                                const float* __restrict__ bscale,
+                                                                const float* __restrict__ a_scale /* (N, Cl) | NULL */,
+                                                                const float* __restrict__ a_shift) {
   __shared__ __attribute__((aligned(16))) unsigned char sA[TERMS][128 * GPITCH];
   __shared__ __attribute__((aligned(16))) unsigned char sB[TERMS][128 * GPITCH];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -1323,11 +1325,28 @@ __global__ __launch_bounds__(256, 3) void up2_wgrad_gemm_kernel(const float* __r
       pb[i][1] = (k + 1 < k_end && cb < J) ? *reinterpret_cast<const float4*>(Bn + (long long)(k + 1) * J + cb) : z4;
     }
   };
-  auto commit = [&]() {
+  // GroupNorm's per-(sample, channel) affine of the A operand, applied while it is staged (a_scale != NULL): the caller
+  // hands over the RAW low tensor and no normalised copy of it is written and read back
+  float4 csc[NIT], csh[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int e = tid + i * 256, cq = (e & 3) + 4 * (e / (4 * NKP)), ca = m0 + 4 * cq;
+    csc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+    csh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a_scale && ca < Cl) {
+      csc[i] = *reinterpret_cast<const float4*>(a_scale + (long long)n * Cl + ca);
+      csh[i] = *reinterpret_cast<const float4*>(a_shift + (long long)n * Cl + ca);
+    }
+  }
+  auto commit = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int e = tid + i * 256, cq = (e & 3) + 4 * (e / (4 * NKP)), kp = (e >> 2) & (NKP - 1);   // (2-way LDS write conflicts at most)
-      const float a0[4] = {pa[i][0].x, pa[i][0].y, pa[i][0].z, pa[i][0].w}, a1[4] = {pa[i][1].x, pa[i][1].y, pa[i][1].z, pa[i][1].w};
+      const bool v0 = k0 + 2 * kp < k_end, v1 = k0 + 2 * kp + 1 < k_end;     // rows past the slab stay zero (no shift)
+      const float a0[4] = {v0 ? fmaf(pa[i][0].x, csc[i].x, csh[i].x) : 0.f, v0 ? fmaf(pa[i][0].y, csc[i].y, csh[i].y) : 0.f,
+                           v0 ? fmaf(pa[i][0].z, csc[i].z, csh[i].z) : 0.f, v0 ? fmaf(pa[i][0].w, csc[i].w, csh[i].w) : 0.f};
+      const float a1[4] = {v1 ? fmaf(pa[i][1].x, csc[i].x, csh[i].x) : 0.f, v1 ? fmaf(pa[i][1].y, csc[i].y, csh[i].y) : 0.f,
+                           v1 ? fmaf(pa[i][1].z, csc[i].z, csh[i].z) : 0.f, v1 ? fmaf(pa[i][1].w, csc[i].w, csh[i].w) : 0.f};
       const float b0[4] = {pb[i][0].x, pb[i][0].y, pb[i][0].z, pb[i][0].w}, b1[4] = {pb[i][1].x, pb[i][1].y, pb[i][1].z, pb[i][1].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1344,7 +1363,7 @@ __global__ __launch_bounds__(256, 3) void up2_wgrad_gemm_kernel(const float* __r
   fetch(k_beg);
   for (int k0 = k_beg; k0 < k_end; k0 += GK) {
     __syncthreads();                           // the previous step's fragment reads are done
-    commit();
+    commit(k0);
     __syncthreads();
     if (k0 + GK < k_end) fetch(k0 + GK);       // in flight during the MFMAs
 #pragma unroll
@@ -1419,15 +1438,19 @@ KMH_API size_t kmh_up2_wgrad_gemm_ws_bytes(int N, int V, int Cl, int J) {
 /* C (N, Cl, J) = A^T B per sample: A (N, V, Cl) the normalised low tensor, B (N, V, J) the box sums (kmh_up2_boxsum);
  * Cl % 4 == 0, J % 4 == 0; ascale / bscale = {S, 1/S} range scales of A and B (terms == 2). */
 KMH_API int kmh_up2_wgrad_gemm(const float* A, const float* B, float* C, int N, int V, int Cl, int J, int terms,
-                               const float* ascale, const float* bscale, void* ws, void* stream) {
-  if ((Cl & 3) || (J & 3) || (terms != 2 && terms != 3) || (terms == 2 && (!ascale || !bscale))) return -22;
+                               const float* ascale, const float* bscale, const float* a_scale, const float* a_shift,
+                               void* ws, void* stream) {
+  if ((Cl & 3) || (J & 3) || (terms != 2 && terms != 3) || (terms == 2 && (!ascale || !bscale)) || (!a_scale != !a_shift))
+    return -22;
   int ks;
   const int ns = up2_wgrad_slabs(V, Cl, J, N, &ks);
   const int ntn = ceil_div(J, 128), ntm = ceil_div(Cl, 128);
   hipStream_t s = (hipStream_t)stream;
   dim3 g(ntn * ntm * ns, 1, N);
-  if (terms == 2) up2_wgrad_gemm_kernel<2><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale);
-  else up2_wgrad_gemm_kernel<3><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale);
+  if (terms == 2)
+    up2_wgrad_gemm_kernel<2><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale, a_scale, a_shift);
+  else
+    up2_wgrad_gemm_kernel<3><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale, a_scale, a_shift);
   const long long per = (long long)Cl * J;
   int nb = ceil_div(per, 256);
   if (nb > 1024) nb = 1024;

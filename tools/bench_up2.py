@@ -29,7 +29,7 @@ for (D, Cs, Cl, Cout) in ((128, 64, 128, 64), (64, 128, 256, 128)):
     ws = torch.empty(int(lib.kmh_up2_wgrad_gemm_ws_bytes(N, Vl, Cl, 27 * Cout)), dtype=torch.uint8, device=dev)
     sa, sb = B.absmax_scale(A), B.absmax_scale(Bx)
     st = torch.cuda.current_stream().cuda_stream
-    f = lambda: lib.kmh_up2_wgrad_gemm(A.data_ptr(), Bx.data_ptr(), C.data_ptr(), N, Vl, Cl, 27 * Cout, 2, sa.data_ptr(), sb.data_ptr(), ws.data_ptr(), st)
+    f = lambda: lib.kmh_up2_wgrad_gemm(A.data_ptr(), Bx.data_ptr(), C.data_ptr(), N, Vl, Cl, 27 * Cout, 2, sa.data_ptr(), sb.data_ptr(), None, None, ws.data_ptr(), st)
     for _ in range(2): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
