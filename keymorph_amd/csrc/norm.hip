@@ -770,11 +770,79 @@ __global__ __launch_bounds__(256, 3) void up2_boxsum_kernel(const float* __restr
   }
 }
 
+// LDS-tiled variant (the default): workgroup = a 4 x 4 x 2 tile of low voxels x 32 channels.  The kernel above reads every dz
+// value ~12 times through L1 (26 GB of loads for a 2.1 GB tensor at the 128^3 decoder level); here the tile's 10 x 10 x 6 window is
+// loaded once into LDS (one plane per channel quad, plane stride = 16 B mod 256 B so that the quads of a voxel fall on different
+// banks) and the SAME additions in the SAME order give bit-identical box sums.
+constexpr int BT_X = 4, BT_Y = 4, BT_Z = 2, BT_CQ = 8;
+constexpr int BT_HX = 2 * BT_X + 2, BT_HY = 2 * BT_Y + 2, BT_HZ = 2 * BT_Z + 2, BT_VOX = BT_HX * BT_HY * BT_HZ;   // 600
+constexpr int BT_PLANE = BT_VOX + 1;
+constexpr int BT_TPB = BT_X * BT_Y * BT_Z * 3 * BT_CQ;                                                             // 768
+__global__ __launch_bounds__(BT_TPB) void up2_boxsum_tiled_kernel(const float* __restrict__ dz, float* __restrict__ G, int Dl,
+                                                                  int Hl, int Wl, int Cout, int tiles_x, int tiles_y) {
+  __shared__ float4 sx[BT_CQ * BT_PLANE];
+  const int n = blockIdx.z, chunk = blockIdx.y, tid = threadIdx.x;
+  const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, bz = blockIdx.x / (tiles_x * tiles_y);
+  const int x0 = bx * BT_X, y0 = by * BT_Y, z0 = bz * BT_Z;
+  const int D = 2 * Dl, H = 2 * Hl, W = 2 * Wl;
+  const float* dn = dz + (long long)n * D * H * W * Cout;
+  for (int e = tid; e < BT_VOX * BT_CQ; e += BT_TPB) {
+    const int q = e & (BT_CQ - 1), v = e / BT_CQ;
+    const int lx = v % BT_HX, ly = (v / BT_HX) % BT_HY, lz = v / (BT_HX * BT_HY);
+    const int ux = 2 * x0 - 1 + lx, uy = 2 * y0 - 1 + ly, uz = 2 * z0 - 1 + lz, c = (chunk * BT_CQ + q) * 4;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)ux < (unsigned)W && (unsigned)uy < (unsigned)H && (unsigned)uz < (unsigned)D && c < Cout)
+      val = *reinterpret_cast<const float4*>(dn + (((long long)uz * H + uy) * W + ux) * Cout + c);
+    sx[q * BT_PLANE + v] = val;
+  }
+  __syncthreads();
+  const int q = tid & (BT_CQ - 1), kz = (tid / BT_CQ) % 3, m = tid / (3 * BT_CQ);
+  const int lmx = m % BT_X, lmy = (m / BT_X) % BT_Y, lmz = m / (BT_X * BT_Y);
+  const int mx = x0 + lmx, my = y0 + lmy, mz = z0 + lmz, c = (chunk * BT_CQ + q) * 4;
+  if (mx >= Wl || my >= Hl || mz >= Dl || c >= Cout) return;
+  const float4* sq = sx + q * BT_PLANE;
+  float4 Y[3][3];
+#pragma unroll
+  for (int a = 0; a < 9; ++a) (&Y[0][0])[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int dzp = 0; dzp < 2; ++dzp) {
+    const int lz = 2 * lmz + (2 - kz) + dzp;
+#pragma unroll
+    for (int iy = 0; iy < 4; ++iy) {
+      const float4* row = sq + (lz * BT_HY + 2 * lmy + iy) * BT_HX + 2 * lmx;
+      const float4 a4[4] = {row[0], row[1], row[2], row[3]};
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float4 u = a4[2 - kx], v = a4[3 - kx];
+        const float4 xs = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+          if (iy == 2 - ky || iy == 3 - ky) {
+            Y[ky][kx].x += xs.x; Y[ky][kx].y += xs.y; Y[ky][kx].z += xs.z; Y[ky][kx].w += xs.w;
+          }
+      }
+    }
+  }
+  const long long mg = ((long long)mz * Hl + my) * Wl + mx;
+  float* o = G + ((long long)n * Dl * Hl * Wl * 27 + mg * 27 + kz * 9) * Cout + c;
+#pragma unroll
+  for (int a = 0; a < 9; ++a) *reinterpret_cast<float4*>(o + (long long)a * Cout) = (&Y[0][0])[a];
+}
+
 /* G (N, Dl*Hl*Wl, 27, Cout) from dz (N, 2Dl, 2Hl, 2Wl, Cout), Cout % 4 == 0 (see the kernel comment): the weight gradient
  * of a 3x3x3 convolution with respect to nearest-x2 upsampled input channels is then x_low^T (Cl x V_low) times G
  * (V_low x 27 Cout) per sample -- one plain matrix product (the host uses the library GEMM). */
 KMH_API int kmh_up2_boxsum(const float* dz, float* G, int N, int Dl, int Hl, int Wl, int Cout, void* stream) {
   if (Cout & 3) return -22;
+  static const bool plain = getenv("KEYMORPH_BOXSUM_PLAIN") != nullptr;       // A/B runs: the untiled kernel
+  if (!plain) {
+    const int tx = (Wl + BT_X - 1) / BT_X, ty = (Hl + BT_Y - 1) / BT_Y, tz = (Dl + BT_Z - 1) / BT_Z;
+    const int chunks = (Cout + 4 * BT_CQ - 1) / (4 * BT_CQ);
+    if ((long long)tx * ty * tz < (1ll << 31) && chunks < 65536 && N < 65536) {
+      up2_boxsum_tiled_kernel<<<dim3(tx * ty * tz, chunks, N), BT_TPB, 0, (hipStream_t)stream>>>(dz, G, Dl, Hl, Wl, Cout, tx, ty);
+      return KMH_LAUNCH_CHECK();
+    }
+  }
   const long long total = (long long)Dl * Hl * Wl * 3 * (Cout / 4);
   up2_boxsum_kernel<<<dim3(stream_blocks(total), N), 256, 0, (hipStream_t)stream>>>(dz, G, Dl, Hl, Wl, Cout);
   return KMH_LAUNCH_CHECK();

@@ -686,6 +686,38 @@ def test_decoder_conv_without_the_upsampled_tensor(cfg, mode, monkeypatch):
         B.set_conv_mode(old)
 
 
+@pytest.mark.parametrize("cfg", [(2, (5, 6, 9), 24), (1, (4, 4, 2), 64), (2, (3, 7, 8), 40), (1, (8, 8, 8), 128)])
+def test_up2_box_sums(cfg):
+    """kmh_up2_boxsum (csrc/norm.hip): G[m][tap][co] = sum of dz over the 2 x 2 x 2 voxels v with (v + tap - 1) // 2 == m, zero
+    outside the volume -- what turns the weight gradient of conv3(up2(x_low)) into x_low^T G (the autograd of
+    keymorph/unet3d/buildingblocks.py:471-475 + :46-78 for the upsampled channels).  The LDS-tiled kernel against a torch
+    restatement (ragged low shapes: partial tiles on every axis; Cout not a multiple of the 32-channel chunk)."""
+    from keymorph_amd import _lib
+    from keymorph_amd.backbone_ops import _p, _stream, check
+    lib = _lib.load()
+    N, ld, Cout = cfg
+    g = gen(53)
+    dz = torch.randn(N, 2 * ld[0], 2 * ld[1], 2 * ld[2], Cout, generator=g)
+    G = torch.full((N, ld[0] * ld[1] * ld[2], 27, Cout), float("nan"), device=DEV)
+    dzd = dz.to(DEV)
+    check(lib.kmh_up2_boxsum(_p(dzd), _p(G), N, ld[0], ld[1], ld[2], Cout, _stream()), "kmh_up2_boxsum")
+    pad = F.pad(dz.double().permute(0, 4, 1, 2, 3), (2, 2, 2, 2, 2, 2))            # (N, C, D + 4, H + 4, W + 4): index u + 2
+    ref = torch.empty(N, ld[0], ld[1], ld[2], 27, Cout, dtype=torch.float64)
+    for kz in range(3):
+        for ky in range(3):
+            for kx in range(3):
+                acc = 0
+                for a in (0, 1):
+                    for b in (0, 1):
+                        for c in (0, 1):        # per axis the hi voxels u = 2 m + 1 - k + {0, 1}
+                            acc = acc + pad[:, :, 3 - kz + a:3 - kz + a + 2 * ld[0]:2, 3 - ky + b:3 - ky + b + 2 * ld[1]:2,
+                                            3 - kx + c:3 - kx + c + 2 * ld[2]:2]
+                ref[:, :, :, :, (kz * 3 + ky) * 3 + kx] = acc.permute(0, 2, 3, 4, 1)
+    got = G.cpu().double().reshape(N, ld[0], ld[1], ld[2], 27, Cout)
+    assert bool(torch.isfinite(got).all())
+    close(got, ref, 1e-5, 1e-6)
+
+
 @pytest.mark.parametrize("cfg", [(2, 16, 24, 32, (3, 5, 18)), (1, 8, 40, 72, (4, 4, 33)), (1, 64, 136, 64, (2, 8, 32))])
 @pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
 def test_up2_data_gradient_at_low_resolution(cfg, mode):
