@@ -425,6 +425,38 @@ __global__ __launch_bounds__(TPB) void maxpool_bwd4_kernel(const unsigned* __res
   }
 }
 
+// Channel-blocked output without a second gradient (the 256^3 level: 8.6 GB written): lane = one 16-byte piece of an output
+// row in memory order (piece p = 4 xo + 2 dx + quad-in-chunk), so every store instruction writes 1 KB of CONTIGUOUS output;
+// the kernel above hands the same bytes over in 32-byte pieces on four planes (2.6 ms = 3.3 TB/s).  Each lane loads its
+// (pooled voxel, quad) winners + gradient (shared with the dx twin through L1) and writes the four (dz, dy) children.
+__global__ __launch_bounds__(TPB) void maxpool_bwd4_rows_kernel(const unsigned* __restrict__ argm, const float4* __restrict__ dy,
+                                                                float* __restrict__ dx, int D, int H, int W, int C4, int Do,
+                                                                int Ho, int Wo) {
+  const int n = blockIdx.y;
+  const long long V = (long long)D * H * W;
+  const long long pooled = (long long)Do * Ho * Wo * C4;
+  float* dxn = dx + (long long)n * V * C4 * 4;
+  const int ppr = Wo * 4;                                   // pieces per pooled row
+  const long long total = (long long)(C4 >> 1) * Do * Ho * ppr;
+  for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+    const int p = (int)(e % ppr);
+    const long long r = e / ppr;
+    const int yo = (int)(r % Ho), zo = (int)((r / Ho) % Do), chunk = (int)(r / ((long long)Ho * Do));
+    const int xo = p >> 2, dxx = (p >> 1) & 1, qh = p & 1;
+    const long long idx = (((long long)zo * Ho + yo) * Wo + xo) * C4 + 2 * chunk + qh;
+    const unsigned a = argm[(long long)n * pooled + idx];
+    const float4 g = dy[(long long)n * pooled + idx];
+    const int a0 = a & 255, a1 = (a >> 8) & 255, a2 = (a >> 16) & 255, a3 = a >> 24;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = 2 * kk + dxx;                            // window index (dz, dy, dx)
+      const long long vox = ((long long)(2 * zo + (kk >> 1)) * H + 2 * yo + (kk & 1)) * W + 2 * xo + dxx;
+      const float4 val = make_float4(k == a0 ? g.x : 0.f, k == a1 ? g.y : 0.f, k == a2 ? g.z : 0.f, k == a3 ? g.w : 0.f);
+      *reinterpret_cast<float4*>(dxn + ((long long)chunk * V + vox) * 8 + 4 * qh) = val;
+    }
+  }
+}
+
 // Pooling backward + skip gradient, with the skip gradient's GroupNorm backward still pending (round 3): the decoder's
 // fused upsample + concat + conv operator returns its normalised-input gradient dxn for the skip half untouched, and this
 // kernel forms  dx = scatter(dy) + [x > 0] (c1 dxn + c2 x + c3)  in one pass over the encoder output x -- the separate
@@ -886,6 +918,12 @@ KMH_API int kmh_maxpool3d_bwd(const float* x, const unsigned char* argmax, const
   const bool aligned = (((uintptr_t)add | (uintptr_t)dx | (uintptr_t)dy) & 15) == 0 && ((uintptr_t)argmax & 3) == 0;
   if (argmax && aligned && (C & 3) == 0 && (add_cstride & 3) == 0 && pooled / 4 < (1ll << 31) &&
       (long long)D * H * W < (1ll << 31)) {
+    static const bool pieces32 = getenv("KEYMORPH_POOL_BWD_PLANES") != nullptr;    // A/B runs: the per-plane 32-byte stores
+    if (out_blocked && !add && !pieces32) {
+      maxpool_bwd4_rows_kernel<<<dim3(stream_blocks(pooled), N), TPB, 0, (hipStream_t)stream>>>(
+          (const unsigned*)argmax, (const float4*)dy, dx, D, H, W, C / 4, Do, Ho, Wo);
+      return KMH_LAUNCH_CHECK();
+    }
     auto kern = out_blocked ? maxpool_bwd4_kernel<true> : maxpool_bwd4_kernel<false>;
     kern<<<dim3(stream_blocks(pooled), N), TPB, 0, (hipStream_t)stream>>>((const unsigned*)argmax, (const float4*)dy, add,
                                                                          add_cstride, dx, D, H, W, C / 4, Do, Ho, Wo);

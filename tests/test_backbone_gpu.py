@@ -845,6 +845,32 @@ def test_unet_gradients_identical_with_and_without_blocked_handoffs(monkeypatch)
         B.set_conv_mode(old)
 
 
+@pytest.mark.parametrize("cfg", [(2, (4, 6, 10), 8), (1, (6, 4, 32), 32), (3, (2, 2, 6), 16)])
+def test_maxpool_backward_channel_blocked_rows(cfg):
+    """kmh_maxpool3d_bwd with out_blocked and no second gradient (the 256^3 level of the step): the row-contiguous kernel
+    writes the (N, C/8, D, H, W, 8) layout of exactly the values the (N, D, H, W, C) kernel writes."""
+    from keymorph_amd import _lib
+    from keymorph_amd.backbone_ops import _p, _stream, check
+    lib = _lib.load()
+    N, dims, C = cfg
+    D, H, W = dims
+    g = gen(71)
+    x = torch.randn(N, D, H, W, C, generator=g).to(DEV)
+    y = torch.empty(N, D // 2, H // 2, W // 2, C, device=DEV)
+    arg = torch.empty(N, D // 2, H // 2, W // 2, C, dtype=torch.uint8, device=DEV)
+    check(lib.kmh_maxpool3d_fwd(_p(x), _p(y), _p(arg), N, D, H, W, C, _stream()), "kmh_maxpool3d_fwd")
+    dy = torch.randn(y.shape, generator=g).to(DEV)
+    dense = torch.full((N, D, H, W, C), float("nan"), device=DEV)
+    blocked = torch.full((N, C // 8, D, H, W, 8), float("nan"), device=DEV)
+    check(lib.kmh_maxpool3d_bwd(None, _p(arg), _p(dy), None, 0, _p(dense), N, D, H, W, C, 0, _stream()), "kmh_maxpool3d_bwd")
+    check(lib.kmh_maxpool3d_bwd(None, _p(arg), _p(dy), None, 0, _p(blocked), N, D, H, W, C, 1, _stream()), "kmh_maxpool3d_bwd")
+    assert torch.equal(blocked.permute(0, 2, 3, 4, 1, 5).reshape(N, D, H, W, C), dense)
+    # and against autograd of max_pool3d
+    xr = ncdhw(x).cpu().double().requires_grad_(True)
+    (F.max_pool3d(xr, 2) * ncdhw(dy).cpu().double()).sum().backward()
+    close(ncdhw(dense), xr.grad, 0, 0)
+
+
 def test_fused_upsample_concat_conv_applies_its_own_relu_mask():
     """upcat_conv_gcr with dy_premasked=False (a consumer that does not mask the gradient it returns): the operator folds
     its ReLU's backward mask itself -- gradients equal PyTorch's."""
