@@ -244,7 +244,10 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
   // ---- gradient row (z, y0 + yy) -> ds[buf][x][co]: global loads split from the LDS stores (the next row is in flight
   // under this row's MFMAs); the pending GroupNorm backward and the ReLU mask are applied on the way
   constexpr int NPRE = 4;                         // float4 items per thread: WP * 4 / FM_TPB <= 4 for W <= 256
-  float4 preA[NPRE], preB[NPRE];                  // two rows in flight: row yy + 1 and row yy + 2
+  // two rows in flight (row yy + 1 and row yy + 2), RAW: gradient and mask operand as loaded.  The GroupNorm backward and the
+  // ReLU mask are applied when the row is written to LDS, a row later -- applied at load time (round 3's first version) every
+  // load_dz waited for its own loads, and the kernel ran at one HBM round trip per row (5.4 us; 3.1 TB/s)
+  float4 preA[NPRE], preB[NPRE], mskA[NPRE], mskB[NPRE];
   float gc[4][3];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -252,38 +255,39 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < 3; ++k) gc[j][k] = (c123 && c < Cout) ? c123[((long long)n * Cout + c) * 3 + k] : 0.f;
   }
-  auto load_dz = [&](int yy, float4 (&pre)[NPRE]) {
+  auto load_dz = [&](int yy, float4 (&pre)[NPRE], float4 (&msk)[NPRE]) {
     const int gy = y0 + yy;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
       const int e = tid + k * FM_TPB;
       const int q = e & 3, xx = e >> 2;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      pre[k] = msk[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (e < WP * 4 && xx < W && gy < H && 4 * q < Cout) {
         const long long off = (((long long)z * H + gy) * W + xx) * Cout + 4 * q;
-        v = *reinterpret_cast<const float4*>(dn + off);
-        if (mn) {
-          const float4 m = *reinterpret_cast<const float4*>(mn + off);
-          if (c123) {            // the same expression as gn_bwd_apply_kernel
-            v.x = gc[0][0] * v.x + gc[0][1] * m.x + gc[0][2];
-            v.y = gc[1][0] * v.y + gc[1][1] * m.y + gc[1][2];
-            v.z = gc[2][0] * v.z + gc[2][1] * m.z + gc[2][2];
-            v.w = gc[3][0] * v.w + gc[3][1] * m.w + gc[3][2];
-          }
-          if (!(m.x > 0.f)) v.x = 0.f;
-          if (!(m.y > 0.f)) v.y = 0.f;
-          if (!(m.z > 0.f)) v.z = 0.f;
-          if (!(m.w > 0.f)) v.w = 0.f;
-        }
+        pre[k] = *reinterpret_cast<const float4*>(dn + off);
+        if (mn) msk[k] = *reinterpret_cast<const float4*>(mn + off);
       }
-      pre[k] = v;
     }
   };
-  auto store_dz = [&](int buf, const float4 (&pre)[NPRE]) {
+  auto store_dz = [&](int buf, const float4 (&pre)[NPRE], const float4 (&msk)[NPRE]) {
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
       const int e = tid + k * FM_TPB;
-      if (e < WP * 4) *reinterpret_cast<float4*>(ds + (buf * WP + (e >> 2)) * 16 + 4 * (e & 3)) = pre[k];
+      float4 v = pre[k];
+      if (mn) {
+        const float4 m = msk[k];
+        if (c123) {            // the same expression as gn_bwd_apply_kernel
+          v.x = gc[0][0] * v.x + gc[0][1] * m.x + gc[0][2];
+          v.y = gc[1][0] * v.y + gc[1][1] * m.y + gc[1][2];
+          v.z = gc[2][0] * v.z + gc[2][1] * m.z + gc[2][2];
+          v.w = gc[3][0] * v.w + gc[3][1] * m.w + gc[3][2];
+        }
+        if (!(m.x > 0.f)) v.x = 0.f;          // (items outside the volume carry m = 0: they stay zero)
+        if (!(m.y > 0.f)) v.y = 0.f;
+        if (!(m.z > 0.f)) v.z = 0.f;
+        if (!(m.w > 0.f)) v.w = 0.f;
+      }
+      if (e < WP * 4) *reinterpret_cast<float4*>(ds + (buf * WP + (e >> 2)) * 16 + 4 * (e & 3)) = v;
     }
   };
   auto stage_dz_scalar = [&](int yy, int buf) {
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
     }
   };
   const bool pipelined = v4 && WP * 4 <= NPRE * FM_TPB;
-  if (pipelined) { load_dz(0, preA); store_dz(0, preA); load_dz(1, preB); } else stage_dz_scalar(0, 0);
+  if (pipelined) { load_dz(0, preA, mskA); store_dz(0, preA, mskA); load_dz(1, preB, mskB); } else stage_dz_scalar(0, 0);
 
   // ---- MFMA operands of this lane: A row i = tap (two tiles), K index k = voxel within the group of 4
   const int ai = lane & 15, ak = lane >> 4;
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
   for (int yy = 0; yy < FM_YR; ++yy) {
     // rows yy + 1 (issued an iteration ago) and yy + 2 (issued now) are in flight under this row's MFMAs
     if (pipelined) {
-      if (yy + 2 < FM_YR) { if (yy & 1) load_dz(yy + 2, preB); else load_dz(yy + 2, preA); }
+      if (yy + 2 < FM_YR) { if (yy & 1) load_dz(yy + 2, preB, mskB); else load_dz(yy + 2, preA, mskA); }
     } else if (yy + 1 < FM_YR) stage_dz_scalar(yy + 1, (yy + 1) & 1);
     if (yy > 0) s_update(yy - 1);
     const float* xr = xs + yy * XP;
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(FM_TPB) void first_wgrad_mfma_kernel(const float* _
 #pragma unroll
     for (int r = 0; r < 4; ++r) { racc0[r] += (double)acc0[r]; racc1[r] += (double)acc1[r]; acc0[r] = 0.f; acc1[r] = 0.f; }
     if (tid < 16) { sfl[(yy & 1) * 32 + tid] = dr[tid]; sfl[(yy & 1) * 32 + 16 + tid] = dr[(W - 1) * 16 + tid]; }
-    if (pipelined && yy + 1 < FM_YR) { if (yy & 1) store_dz((yy + 1) & 1, preA); else store_dz((yy + 1) & 1, preB); }
+    if (pipelined && yy + 1 < FM_YR) { if (yy & 1) store_dz((yy + 1) & 1, preA, mskA); else store_dz((yy + 1) & 1, preB, mskB); }
     __syncthreads();
   }
   s_update(FM_YR - 1);
