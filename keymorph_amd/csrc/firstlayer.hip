@@ -442,16 +442,22 @@ __global__ __launch_bounds__(FF_TPB) void first_fwd_kernel(const float* __restri
   const float sc = scale ? scale[n] : 1.f, sh = scale ? shift[n] : 0.f;
   // tile element e -> (lz, ly, lx); the global load of plane window z is split from its LDS store so that the next
   // window is in flight while this one is multiplied
+  // (the normalisation is applied when the window is written to LDS: applied to the loaded value here, the load would have
+  // to land inside load_tile and every plane would start with an exposed memory round trip)
   float pre[FF_NLD];
+  unsigned pre_in = 0u;                        // bit k: element k of the window lies inside the volume
   auto load_tile = [&](int z) {
+    pre_in = 0u;
 #pragma unroll
     for (int k = 0; k < FF_NLD; ++k) {
       const int e = tid + k * FF_TPB;
       const int lx = e % FF_P, r = e / FF_P, ly = r % (FF_Y + 2), lz = r / (FF_Y + 2);
       const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z + lz - 1;
       float v = 0.f;
-      if (e < FF_TILE && (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D)
-        v = xn[((long long)gz * H + gy) * W + gx] * sc + sh;
+      if (e < FF_TILE && (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D) {
+        v = xn[((long long)gz * H + gy) * W + gx];
+        pre_in |= 1u << k;
+      }
       pre[k] = v;
     }
   };
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(FF_TPB) void first_fwd_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < FF_NLD; ++k) {
       const int e = tid + k * FF_TPB;
-      if (e < FF_TILE) sx[buf][e] = pre[k];
+      if (e < FF_TILE) sx[buf][e] = ((pre_in >> k) & 1u) ? pre[k] * sc + sh : 0.f;      // zero padding AFTER the normalisation
     }
   };
   load_tile(zc);
