@@ -693,12 +693,18 @@ __global__ __launch_bounds__(LU_TPB) void tps_solve_kernel(const double* __restr
       sD[r][c] = (r < nb && c < nb) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;
     }
     __syncthreads();
-    if (tid < 3) {
-      for (int r = 1; r < nb; ++r) {
-        double a = sb[(k0 + r) * 3 + tid];
-        for (int k = 0; k < r; ++k) a -= sD[r][k] * sb[(k0 + k) * 3 + tid];
-        sb[(k0 + r) * 3 + tid] = a;
+    // the block's triangular solve on ONE wave, lane = (row, right-hand side), columns eliminated in order with the solved
+    // value passed by a shuffle (three lanes walking the rows one after the other took ~3.5 us per block: 120 dependent
+    // LDS round trips)
+    if (tid < 64) {
+      const int r = tid / 3, j = tid - 3 * r;
+      const bool act = r < nb;
+      double val = act ? sb[(k0 + r) * 3 + j] : 0.0;
+      for (int k = 0; k + 1 < nb; ++k) {
+        const double xk = __shfl(val, 3 * k + j, 64);
+        if (act && r > k) val -= sD[r][k] * xk;
       }
+      if (act) sb[(k0 + r) * 3 + j] = val;
     }
     __syncthreads();
     for (int r = k0 + nb + tid; r < n; r += LU_TPB) {
@@ -721,12 +727,17 @@ __global__ __launch_bounds__(LU_TPB) void tps_solve_kernel(const double* __restr
       sD[r][c] = (r < nb && c < nb) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;
     }
     __syncthreads();
-    if (tid < 3) {
-      for (int r = nb - 1; r >= 0; --r) {
-        double a = sb[(k0 + r) * 3 + tid];
-        for (int k = r + 1; k < nb; ++k) a -= sD[r][k] * sb[(k0 + k) * 3 + tid];
-        sb[(k0 + r) * 3 + tid] = a / sD[r][r];
+    if (tid < 64) {                                   // as above, from the last column up; the lane of row k divides
+      const int r = tid / 3, j = tid - 3 * r;
+      const bool act = r < nb;
+      double val = act ? sb[(k0 + r) * 3 + j] : 0.0;
+      const double ukk = act ? sD[r][r] : 1.0;
+      for (int k = nb - 1; k >= 0; --k) {
+        if (r == k) val = val / ukk;
+        const double xk = __shfl(val, 3 * k + j, 64);
+        if (act && r < k) val -= sD[r][k] * xk;
       }
+      if (act) sb[(k0 + r) * 3 + j] = val;
     }
     __syncthreads();
     for (int r = tid; r < k0; r += LU_TPB) {
