@@ -489,11 +489,18 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
   __shared__ double s_val[LU_TPB / kWave];
   __shared__ int s_idx[LU_TPB / kWave];
   __shared__ int s_piv[NB];
+  // Row interchanges are NOT carried out in memory: rowmap[i] = the physical (= original) row that currently sits at
+  // position i of the pivoted order.  Every access to a row of A goes through it, a pivot swaps two of its entries, and the
+  // solve reads the same map (ipiv_all receives rowmap, not LAPACK's sequential interchanges).  Swapping the rows of the
+  // columns outside the panel in global memory was 16 dependent load / store round trips per panel and thread.
+  int* rowmap = reinterpret_cast<int*>(smem + (size_t)n * PS + (size_t)NB * n);     // [n]
   double* A = Aall + (size_t)blockIdx.x * a_stride;
   int* ipiv = ipiv_all + (size_t)blockIdx.x * n;
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1), wid = tid / kWave;
   int bad = 0;
+  for (int e = tid; e < n; e += LU_TPB) rowmap[e] = e;
+  __syncthreads();
 
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int nb = (n - k0 < NB) ? (n - k0) : NB;
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
     // 1. panel -> LDS
     for (int e = tid; e < m * nb; e += LU_TPB) {
       const int r = e / nb, c = e % nb;
-      sP[r * PS + c] = A[(size_t)(k0 + r) * lda + k0 + c];
+      sP[r * PS + c] = A[(size_t)rowmap[k0 + r] * lda + k0 + c];
     }
     __syncthreads();
     // 2. unblocked LU of the panel
@@ -539,6 +546,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
         sP[j * PS + tid] = sP[p * PS + tid];
         sP[p * PS + tid] = t;
       }
+      if (p != j && tid == LU_TPB - 1) { const int t = rowmap[k0 + j]; rowmap[k0 + j] = rowmap[k0 + p]; rowmap[k0 + p] = t; }
       __syncthreads();
       // scale + rank-1 update of the remaining panel columns: one thread per row (rows are
       // private to their thread; row j is read-only here), so no extra barrier is needed
@@ -550,32 +558,20 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
       }
       __syncthreads();
     }
-    // 3. record pivots (absolute) and apply the swaps to the columns outside the panel
-    if (tid < nb) ipiv[k0 + tid] = k0 + s_piv[tid];
-    for (int c = tid; c < n; c += LU_TPB) {
-      if (c >= k0 && c < k0 + nb) continue;
-      for (int j = 0; j < nb; ++j) {
-        const int p = s_piv[j];
-        if (p != j) {
-          const double t = A[(size_t)(k0 + j) * lda + c];
-          A[(size_t)(k0 + j) * lda + c] = A[(size_t)(k0 + p) * lda + c];
-          A[(size_t)(k0 + p) * lda + c] = t;
-        }
-      }
-    }
+    // 3. (no interchanges in memory: rowmap)
     // 4. panel back to global
     for (int e = tid; e < m * nb; e += LU_TPB) {
       const int r = e / nb, c = e % nb;
-      A[(size_t)(k0 + r) * lda + k0 + c] = sP[r * PS + c];
+      A[(size_t)rowmap[k0 + r] * lda + k0 + c] = sP[r * PS + c];
     }
-    __syncthreads();  // swaps visible (same workgroup, global memory) before U12 reads
+    __syncthreads();
     const int ncols = n - k0 - nb;
     if (ncols > 0) {
       // 5. U12 = L11^-1 A12, one thread per column
       for (int c = tid; c < ncols; c += LU_TPB) {
         double col[NB];
 #pragma unroll
-        for (int r = 0; r < NB; ++r) col[r] = (r < nb) ? A[(size_t)(k0 + r) * lda + k0 + nb + c] : 0.0;
+        for (int r = 0; r < NB; ++r) col[r] = (r < nb) ? A[(size_t)rowmap[k0 + r] * lda + k0 + nb + c] : 0.0;
 #pragma unroll
         for (int r = 1; r < NB; ++r) {
           double a = col[r];
@@ -585,7 +581,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
         }
 #pragma unroll
         for (int r = 0; r < NB; ++r)
-          if (r < nb) { sU[r * n + c] = col[r]; A[(size_t)(k0 + r) * lda + k0 + nb + c] = col[r]; }
+          if (r < nb) { sU[r * n + c] = col[r]; A[(size_t)rowmap[k0 + r] * lda + k0 + nb + c] = col[r]; }
       }
       __syncthreads();
       // 6. trailing update A22 -= L21 U12.
@@ -605,7 +601,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int r = r0 + lk + 4 * q, c = c0 + li;
-            oldv[q] = (r < ncols && c < ncols) ? A[(size_t)(k0 + nb + r) * lda + k0 + nb + c] : 0.0;
+            oldv[q] = (r < ncols && c < ncols) ? A[(size_t)rowmap[k0 + nb + r] * lda + k0 + nb + c] : 0.0;
           }
 #pragma unroll
           for (int s4 = 0; s4 < NB / 4; ++s4) {
@@ -617,7 +613,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int r = r0 + lk + 4 * q, c = c0 + li;
-            if (r < ncols && c < ncols) A[(size_t)(k0 + nb + r) * lda + k0 + nb + c] = oldv[q] - acc[q];
+            if (r < ncols && c < ncols) A[(size_t)rowmap[k0 + nb + r] * lda + k0 + nb + c] = oldv[q] - acc[q];
           }
         }
       } else {
@@ -646,12 +642,13 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (r0 + i < ncols && c0 + j < ncols)
-              A[(size_t)(k0 + nb + r0 + i) * lda + k0 + nb + c0 + j] -= acc[i][j];
+              A[(size_t)rowmap[k0 + nb + r0 + i] * lda + k0 + nb + c0 + j] -= acc[i][j];
       }
       }
     }
     __syncthreads();
   }
+  for (int e = tid; e < n; e += LU_TPB) ipiv[e] = rowmap[e];
   if (tid == 0) info_all[blockIdx.x] = bad;
 }
 
@@ -672,17 +669,11 @@ __global__ __launch_bounds__(LU_TPB) void tps_solve_kernel(const double* __restr
   const double* A = Aall + (size_t)blockIdx.x * a_stride;
   const int* ipiv = ipiv_all + (size_t)blockIdx.x * n;
   const int tid = threadIdx.x;
-  for (int e = tid; e < n * 3; e += LU_TPB) {
-    const int r = e / 3;
-    sb[e] = (r < rhs_rows) ? (double)rhs[(size_t)blockIdx.x * rhs_rows * 3 + e] : 0.0;
-  }
-  for (int e = tid; e < n; e += LU_TPB) spiv[e] = ipiv[e];
+  for (int e = tid; e < n; e += LU_TPB) spiv[e] = ipiv[e];          // the factorisation's row map (tps_lu_kernel)
   __syncthreads();
-  if (tid < 3) {  // apply the row interchanges in order (one lane per right-hand side)
-    for (int k = 0; k < n; ++k) {
-      const int p = spiv[k];
-      if (p != k) { const double t = sb[k * 3 + tid]; sb[k * 3 + tid] = sb[p * 3 + tid]; sb[p * 3 + tid] = t; }
-    }
+  for (int e = tid; e < n * 3; e += LU_TPB) {                      // P b: position i of the pivoted order takes row spiv[i]
+    const int r = spiv[e / 3], j = e % 3;
+    sb[e] = (r < rhs_rows) ? (double)rhs[((size_t)blockIdx.x * rhs_rows + r) * 3 + j] : 0.0;
   }
   __syncthreads();
   // forward: L y = b (unit lower)
@@ -690,7 +681,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_solve_kernel(const double* __restr
     const int nb = (n - k0 < SB) ? (n - k0) : SB;
     if (tid < SB * SB) {
       const int r = tid / SB, c = tid % SB;
-      sD[r][c] = (r < nb && c < nb) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;
+      sD[r][c] = (r < nb && c < nb) ? A[(size_t)spiv[k0 + r] * lda + k0 + c] : 0.0;
     }
     __syncthreads();
     // the block's triangular solve on ONE wave, lane = (row, right-hand side), columns eliminated in order with the solved
@@ -708,9 +699,10 @@ __global__ __launch_bounds__(LU_TPB) void tps_solve_kernel(const double* __restr
     }
     __syncthreads();
     for (int r = k0 + nb + tid; r < n; r += LU_TPB) {
+      const double* Arow = A + (size_t)spiv[r] * lda;
       double a0 = 0, a1 = 0, a2 = 0;
       for (int k = 0; k < nb; ++k) {
-        const double l = A[(size_t)r * lda + k0 + k];
+        const double l = Arow[k0 + k];
         a0 += l * sb[(k0 + k) * 3]; a1 += l * sb[(k0 + k) * 3 + 1]; a2 += l * sb[(k0 + k) * 3 + 2];
       }
       sb[r * 3] -= a0; sb[r * 3 + 1] -= a1; sb[r * 3 + 2] -= a2;
@@ -724,7 +716,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_solve_kernel(const double* __restr
     const int nb = (n - k0 < SB) ? (n - k0) : SB;
     if (tid < SB * SB) {
       const int r = tid / SB, c = tid % SB;
-      sD[r][c] = (r < nb && c < nb) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;
+      sD[r][c] = (r < nb && c < nb) ? A[(size_t)spiv[k0 + r] * lda + k0 + c] : 0.0;
     }
     __syncthreads();
     if (tid < 64) {                                   // as above, from the last column up; the lane of row k divides
@@ -741,9 +733,10 @@ __global__ __launch_bounds__(LU_TPB) void tps_solve_kernel(const double* __restr
     }
     __syncthreads();
     for (int r = tid; r < k0; r += LU_TPB) {
+      const double* Urow = A + (size_t)spiv[r] * lda;
       double a0 = 0, a1 = 0, a2 = 0;
       for (int k = 0; k < nb; ++k) {
-        const double u = A[(size_t)r * lda + k0 + k];
+        const double u = Urow[k0 + k];
         a0 += u * sb[(k0 + k) * 3]; a1 += u * sb[(k0 + k) * 3 + 1]; a2 += u * sb[(k0 + k) * 3 + 2];
       }
       sb[r * 3] -= a0; sb[r * 3 + 1] -= a1; sb[r * 3 + 2] -= a2;
@@ -937,7 +930,7 @@ KMH_API size_t kmh_tps_fit_ws_bytes(int N, int T) {
 
 template <int NB>
 static int launch_lu(const FitWs& f, int N, int n, hipStream_t s) {
-  const size_t lds = ((size_t)n * (NB + 1) + (size_t)NB * n) * sizeof(double);
+  const size_t lds = ((size_t)n * (NB + 1) + (size_t)NB * n) * sizeof(double) + (size_t)n * sizeof(int);   // + rowmap
   if (lds > 160 * 1024 - 1024) return -22;
   static const bool valu_trailing = getenv("KEYMORPH_TPS_LU_VALU") != nullptr;      // A/B measurements only
   if (valu_trailing) {
