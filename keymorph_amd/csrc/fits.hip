@@ -594,26 +594,40 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
         typedef double kmh_d4 __attribute__((ext_vector_type(4)));
         const int t16 = (ncols + 15) / 16;
         const int li = lane & 15, lk = lane >> 4;
-        for (int tile = wid; tile < t16 * t16; tile += LU_TPB / kWave) {
-          const int r0 = (tile / t16) * 16, c0 = (tile % t16) * 16;
-          kmh_d4 acc = {0.0, 0.0, 0.0, 0.0};
-          double oldv[4];
+        // TU tiles per trip: their A22 loads are issued together (one tile at a time, every tile started with an exposed
+        // global round trip: ~60 of them per wave and panel at the start of the factorisation)
+        constexpr int TU = 4;
+        constexpr int NWV = LU_TPB / kWave;
+        for (int tile0 = wid; tile0 < t16 * t16; tile0 += NWV * TU) {
+          double oldv[TU][4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int r = r0 + lk + 4 * q, c = c0 + li;
-            oldv[q] = (r < ncols && c < ncols) ? A[(size_t)rowmap[k0 + nb + r] * lda + k0 + nb + c] : 0.0;
+          for (int u = 0; u < TU; ++u) {
+            const int tile = tile0 + u * NWV;
+            const int r0 = (tile / t16) * 16, c0 = (tile % t16) * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int r = r0 + lk + 4 * q, c = c0 + li;
+              oldv[u][q] = (tile < t16 * t16 && r < ncols && c < ncols) ? A[(size_t)rowmap[k0 + nb + r] * lda + k0 + nb + c] : 0.0;
+            }
           }
 #pragma unroll
-          for (int s4 = 0; s4 < NB / 4; ++s4) {
-            const int k = 4 * s4 + lk;
-            const double a = (r0 + li < ncols && k < nb) ? sP[(nb + r0 + li) * PS + k] : 0.0;
-            const double b = (c0 + li < ncols && k < nb) ? sU[k * n + c0 + li] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-          }
+          for (int u = 0; u < TU; ++u) {
+            const int tile = tile0 + u * NWV;
+            if (tile >= t16 * t16) break;                      // wave-uniform
+            const int r0 = (tile / t16) * 16, c0 = (tile % t16) * 16;
+            kmh_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int r = r0 + lk + 4 * q, c = c0 + li;
-            if (r < ncols && c < ncols) A[(size_t)rowmap[k0 + nb + r] * lda + k0 + nb + c] = oldv[q] - acc[q];
+            for (int s4 = 0; s4 < NB / 4; ++s4) {
+              const int k = 4 * s4 + lk;
+              const double a = (r0 + li < ncols && k < nb) ? sP[(nb + r0 + li) * PS + k] : 0.0;
+              const double b = (c0 + li < ncols && k < nb) ? sU[k * n + c0 + li] : 0.0;
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int r = r0 + lk + 4 * q, c = c0 + li;
+              if (r < ncols && c < ncols) A[(size_t)rowmap[k0 + nb + r] * lda + k0 + nb + c] = oldv[u][q] - acc[q];
+            }
           }
         }
       } else {
