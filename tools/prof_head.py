@@ -2,6 +2,9 @@
 stored-sign-mask backward and with the recomputing one; KMH_TRACE=1 wraps nothing -- run under rocprofv3 for kernels"""
 import sys, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+if __import__("os").environ.get("KMH_LIB"):
+    from keymorph_amd import _lib as _l
+    _l.LIBPATH = __import__("os").environ["KMH_LIB"]
 from keymorph_amd import backbone_ops as B
 B.set_conv_mode("f16x3")
 dev = "cuda"
