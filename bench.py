@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: volume-pairs/sec, forward+backward(+Adam), 256^3, 512 keypoints, TPS lambda=0.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched via torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS
+one of the N ranks; started plainly (`python bench.py --gpus N`, WORLD_SIZE unset) it starts the N ranks itself (self_launch)
+and refuses -- exit code 2 -- when fewer than N devices are visible.  Either way the line says n_gpus = rccl_ranks = N.
 
 One "step" = one training step of scripts/train.py:102-176 restated on this package: KeyMorph.forward
 (TruncatedUNet3D on [fixed; moving] -> center of mass -> TPS fit -> dense grid) -> align_img -> MSE ->
@@ -46,10 +50,10 @@ def parse():
                          "64 thr 6.46, 128 thr 12.05, 256 thr 73.7 -- ATen / oneDNN oversubscribe, so the fastest "
                          "setting is the default and the count actually used is reported as `cores`")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="bound of the cpu_baseline sample")
-    ap.add_argument("--also-f32", type=int, default=1,
+    ap.add_argument("--also-f32", type=int, default=3,
                     help="N > 0: also time N steps with the exact fp32-MFMA convolutions (v_mfma_f32_32x32x2_f32) and "
                          "report them as f32_mfma_* next to the f16x3 headline (N = 1 rank only)")
-    ap.add_argument("--dice", type=int, default=1,
+    ap.add_argument("--dice", type=int, default=3,
                     help="N > 0: also time N steps of the Dice branch (scripts/train.py:146-164: a 14-class one-hot "
                          "segmentation warped with the same grid + DiceLoss as the loss) -> dice_pairs_per_s")
     ap.add_argument("--eval-steps", type=int, default=3,
@@ -58,13 +62,66 @@ def parse():
     ap.add_argument("--groupwise", type=int, default=8,
                     help="S > 0: also time KeyMorph.groupwise_register over S synthetic subjects at --size (BASELINE "
                          "configs[4]: 8 subjects, 512 keypoints, TPS, num_iters 5) -> groupwise_subjects_per_s")
-    ap.add_argument("--convnet", type=int, default=1,
+    ap.add_argument("--convnet", type=int, default=3,
                     help="N > 0: also time N training steps with the ConvNet(instance norm) backbone (keymorph/net.py:7-36)")
     ap.add_argument("--sampler", type=int, default=1, help="report stand-alone align_img GB/s for C = 1 and C = 14")
     ap.add_argument("--cpu-256", type=int, default=1,
                     help="1: also time the oracle ONCE at the metric's shape (size^3, 512 keypoints, affine, fwd+bwd; "
                          "~1 min, ~50 GB of host RAM; skipped when less than 96 GB is available)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def visible_devices():
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher (the way the driver calls --gpus 1): start the N ranks here, one per visible
+    device, rendezvous on 127.0.0.1 -- what scripts/run.py:390 (nn.DataParallel) is replaced by.  Rank 0 inherits stdout (the
+    ONE JSON line); the other ranks' stdout is folded into stderr.  Any rank failing ends the job non-zero.
+    Test hooks (1-GPU / CPU boxes only): KEYMORPH_SHARE_GPU=1 + KEYMORPH_DIST_BACKEND=gloo put every rank on device 0;
+    KEYMORPH_BENCH_LAUNCH_CHECK=1 stops every rank after the process group's first collective (no HIP work: runs on CPU)."""
+    import subprocess
+    n = a.gpus
+    ndev = visible_devices()
+    hooks = os.environ.get("KEYMORPH_SHARE_GPU") == "1" or os.environ.get("KEYMORPH_BENCH_LAUNCH_CHECK") == "1"
+    if ndev < n and not hooks:
+        print(f"bench.py: --gpus {n} needs {n} visible devices, this box shows {ndev}; refusing to print a line that "
+              f"would say n_gpus {ndev or 1}", file=sys.stderr)
+        sys.exit(2)
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KEYMORPH_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                print(f"bench.py: rank {procs.index(p)} exited with {c}; stopping the other ranks", file=sys.stderr)
+                for q in live:            # exactly the PIDs started above
+                    q.terminate()
+    sys.exit(rc)
 
 
 def build_model(K, device):
@@ -199,21 +256,12 @@ def cpu_baseline(threads, seconds, big_size=0, big_kp=512):
         if avail >= 96:
             # BASELINE configs[1] shape on the host: the same synthetic pair recipe as the GPU legs (blob volume and an
             # affine-warped copy, generated on the CPU by the oracle), 512 keypoints, affine aligner, fwd + bwd, MSE;
-            # ONE pair, no warm-up (the process is warm from the 128^3 sample; a pair is tens of seconds)
-            from keymorph_amd import synthetic
-            cpu_dev = torch.device("cpu")
-            fb = synthetic.blob_volume(big_size, 100, cpu_dev)
-            gridb = O.affine_grid(torch.inverse(synthetic.random_affine_matrix(100, cpu_dev)), (big_size,) * 3)
-            mb = O.align_img(gridb, fb)
-            del gridb
-            sdb = {k: v.requires_grad_(True) for k, v in seeded_state_dict(unet_shapes(big_kp, 32, trunc=1), 23).items()}
-            tb = time.time()
-            rb = O.keymorph_forward(lambda x: O.unet3d_forward(sdb, x, 4, 1, 8), fb, mb, "affine")
-            t_fwd = time.time() - tb
-            O.mse_loss(fb, O.align_img(rb["grid"], mb)).backward()
-            big = {"seconds_per_pair": time.time() - tb, "forward_seconds": t_fwd, "size": big_size, "keypoints": big_kp,
-                   "mem_available_gib": avail}
-            del rb, sdb, fb, mb
+            # ONE pair, no warm-up (the process is warm from the 128^3 sample; a pair is tens of seconds).  The result
+            # is KEPT: main() runs the HIP path on the same pair and weights and reports `parity_at_size`.
+            from tests.oracle_at_size import oracle_pair
+            ref = oracle_pair(big_size, big_kp, threads=nthreads, tt="affine", seed=100, sd_seed=23)
+            big = {"seconds_per_pair": ref["seconds"], "forward_seconds": ref["forward_seconds"], "size": big_size,
+                   "keypoints": big_kp, "mem_available_gib": avail, "ref": ref}
         else:
             big = {"skipped": f"only {avail:.0f} GiB of host RAM available (needs ~50, wants 96)"}
     cpu = platform.processor() or ""
@@ -232,10 +280,30 @@ def cpu_baseline(threads, seconds, big_size=0, big_kp=512):
 
 def main():
     a = parse()
-    from keymorph_amd import _lib, backbone_ops, parallel, synthetic
-    backbone_ops.set_conv_mode(a.conv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)          # does not return
+    launch_check = os.environ.get("KEYMORPH_BENCH_LAUNCH_CHECK") == "1"
+    from keymorph_amd import parallel
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={os.environ.get('WORLD_SIZE')} but --gpus {a.gpus}")
+    if a.gpus > 1 and not launch_check and os.environ.get("KEYMORPH_SHARE_GPU") != "1" and visible_devices() < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} needs {a.gpus} visible devices, this box shows {visible_devices()}", file=sys.stderr)
+        sys.exit(2)
     rank, local, world = parallel.init_distributed()
-    assert world == a.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {a.gpus}"
+    if launch_check:
+        # launcher test hook: the process group the gradients would use, one collective, no HIP work
+        probe = torch.ones(1, device="cuda" if torch.cuda.is_available() else "cpu")
+        if world > 1:
+            torch.distributed.all_reduce(probe)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rccl_ranks": int(probe.item()),
+                              "backend": torch.distributed.get_backend() if world > 1 else None,
+                              "self_launched": os.environ.get("KEYMORPH_BENCH_SELF_LAUNCHED") == "1"}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    from keymorph_amd import _lib, backbone_ops, synthetic
+    backbone_ops.set_conv_mode(a.conv)
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
     _lib.load()
@@ -262,10 +330,24 @@ def main():
         loss = train_step(model, flat, opt, img_f, img_m, tt)
     sync()
     dt = time.perf_counter() - t0
+    rank_ms = [1000 * dt / a.steps]
+    allreduce_ms = 0.0
     if world > 1:
         t = torch.tensor([dt], device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        every = [torch.empty_like(t) for _ in range(world)]
+        torch.distributed.all_gather(every, t)
+        rank_ms = [1000 * float(x.item()) / a.steps for x in every]       # each rank's own clock around the same K steps
+        dt = max(float(x.item()) for x in every)                          # MAX over ranks
+        # the step's only exchange, timed alone: the flat gradient bucket summed over the ranks (RCCL over xGMI)
+        g = flat.grad.clone()
+        torch.distributed.all_reduce(g)
+        sync()
+        ta = time.perf_counter()
+        for _ in range(5):
+            torch.distributed.all_reduce(g)
+        sync()
+        allreduce_ms = 1000 * (time.perf_counter() - ta) / 5
+        del g
     loss_val = float(loss.item())
     # a step timed on non-finite parameters would be a measurement of nothing (lambda = 0 TPS is singular once two
     # keypoints coincide): refuse to report it
@@ -303,12 +385,40 @@ def main():
         extra.update({"f32_mfma_ms_per_step": 1000 * dt_f, "f32_mfma_pairs_per_s": a.pairs_per_gpu * world / dt_f,
                       "f32_mfma_note": f"same step with KEYMORPH_HIP_CONV=f32 (v_mfma_f32_32x32x2_f32, no operand "
                                        f"splitting), {a.also_f32} timed step(s)"})
-    def side_leg(name, fn):
-        """the side figures must never cost the headline line: a failure is reported under `<name>_error`"""
+    def agree(ok):
+        """True iff every rank says ok (one MIN all-reduce; ranks must reach this together)"""
+        if world == 1:
+            return bool(ok)
+        f = torch.tensor([1.0 if ok else 0.0], device=dev)
+        torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MIN)
+        return bool(f.item() > 0.5)
+
+    def max_over_ranks(t):
+        if world == 1:
+            return t
+        tt_ = torch.tensor([t], device=dev)
+        torch.distributed.all_reduce(tt_, op=torch.distributed.ReduceOp.MAX)
+        return float(tt_.item())
+
+    def side_leg(name, fn, need_gib=0.0):
+        """The side figures must never cost the headline line: a failure is reported under `<name>_error`.  `fn` does this
+        rank's work and returns (seconds, finish) -- `finish(seconds_max_over_ranks)` files the figures.  Under N > 1 the
+        ranks first agree that every one of them has `need_gib` of free HBM (a leg with a collective inside -- groupwise's
+        all-gather -- is skipped everywhere rather than entered by some ranks), and agree on success BEFORE the timing
+        reduction, so that one rank's failure cannot leave the others waiting in a collective."""
+        free = (torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated()) / 2 ** 30
+        if not agree(free >= need_gib):
+            extra[name + "_error"] = f"skipped: a rank has less than {need_gib:.0f} GiB of free HBM (this rank: {free:.0f})"
+            return
+        t, finish, err = 0.0, None, None
         try:
-            fn()
+            t, finish = fn()
         except Exception as e:      # noqa: BLE001
-            extra[name + "_error"] = f"{type(e).__name__}: {e}"[:300]
+            err = f"{type(e).__name__}: {e}"[:300]
+        if agree(err is None):
+            finish(max_over_ranks(t))
+        else:
+            extra[name + "_error"] = err or "another rank failed"
         torch.cuda.empty_cache()
 
     def eval_leg():
@@ -332,13 +442,10 @@ def main():
             t = (time.perf_counter() - t) / a.eval_steps
         finally:
             model.train()
-        if world > 1:
-            tt_ = torch.tensor([t], device=dev)
-            torch.distributed.all_reduce(tt_, op=torch.distributed.ReduceOp.MAX)
-            t = float(tt_.item())
-        extra.update({"eval_pairs_per_s": a.pairs_per_gpu * world / t, "eval_ms_per_pass": 1000 * t,
-                      "eval_config": f"model.eval(), no_grad, bs={a.pairs_per_gpu} pair(s)/GPU, transform types {types} from "
-                                     f"ONE keypoint extraction, aligned points + align_img per type, {a.eval_steps} timed pass(es)"})
+        return t, lambda t: extra.update({
+            "eval_pairs_per_s": a.pairs_per_gpu * world / t, "eval_ms_per_pass": 1000 * t,
+            "eval_config": f"model.eval(), no_grad, bs={a.pairs_per_gpu} pair(s)/GPU, transform types {types} from "
+                           f"ONE keypoint extraction, aligned points + align_img per type, {a.eval_steps} timed pass(es)"})
 
     def groupwise_leg():
         # BASELINE configs[4]: KeyMorph.groupwise_register (keymorph/model.py:295-530) over S subjects at full size,
@@ -357,24 +464,23 @@ def main():
             with torch.no_grad():
                 return model.groupwise_register(stack, transform_type=[gtype], device=dev, num_iters=iters,
                                                 save_results_to_disk=False)
+        reps = 3
         try:
             r = one()
             sync()
             t = time.perf_counter()
-            r = one()
+            for _ in range(reps):
+                r = one()
             sync()
-            t = time.perf_counter() - t
+            t = (time.perf_counter() - t) / reps
         finally:
             model.train()
-        if world > 1:
-            tt_ = torch.tensor([t], device=dev)
-            torch.distributed.all_reduce(tt_, op=torch.distributed.ReduceOp.MAX)
-            t = float(tt_.item())
         ok = bool(torch.isfinite(r[gtype]["grouppoints_a"]).all())
-        extra.update({"groupwise_subjects_per_s": S / t, "groupwise_ms": 1000 * t, "groupwise_finite": ok,
-                      "groupwise_config": f"BASELINE configs[4]: {S} subjects x {a.size}^3, {a.keypoints} keypoints, {gtype}, "
-                                          f"num_iters {iters}, eval / no_grad, grids kept in HBM; subjects sharded over "
-                                          f"{world} rank(s), one all-gather of the keypoints"})
+        return t, lambda t: extra.update({
+            "groupwise_subjects_per_s": S / t, "groupwise_ms": 1000 * t, "groupwise_finite": ok,
+            "groupwise_config": f"BASELINE configs[4]: {S} subjects x {a.size}^3, {a.keypoints} keypoints, {gtype}, "
+                                f"num_iters {iters}, eval / no_grad, grids kept in HBM; subjects sharded over "
+                                f"{world} rank(s), one all-gather of the keypoints; {reps} timed runs"})
 
     def sampler_leg():
         # stand-alone align_img (keymorph/utils.py:14-21) at the metric's volume size: forward 20 B/voxel for C = 1
@@ -414,7 +520,7 @@ def main():
         out["copy_same_bytes"] = {"ms": ms, "GB": 2 * nb / 1e9, "GBps": 2 * nb / ms / 1e6,
                                   "note": "torch copy_ of the C = 1 warp's algorithmic byte count: what a streaming kernel "
                                           "reaches on this chip at this size"}
-        extra["align_img_standalone"] = out
+        return 0.0, lambda _t: extra.update({"align_img_standalone": out})
 
     def convnet_leg():
         # the reference's other backbone (keymorph/net.py:7-36, instance norm): same step, same sizes
@@ -431,16 +537,18 @@ def main():
             lo = train_step(cm, cflat, copt, img_f, img_m, tt)
         sync()
         t = (time.perf_counter() - t) / a.convnet
-        extra.update({"convnet_pairs_per_s": a.pairs_per_gpu * world / t, "convnet_ms_per_step": 1000 * t,
-                      "convnet_loss": float(lo.item()),
-                      "convnet_config": f"ConvNet(instance norm, 9 blocks, {a.keypoints} keypoints) backbone, same step and "
-                                        f"sizes as the headline, {a.convnet} timed step(s)"})
+        lo = float(lo.item())
+        return t, lambda t: extra.update({
+            "convnet_pairs_per_s": a.pairs_per_gpu * world / t, "convnet_ms_per_step": 1000 * t, "convnet_loss": lo,
+            "convnet_config": f"ConvNet(instance norm, 9 blocks, {a.keypoints} keypoints) backbone, same step and "
+                              f"sizes as the headline, {a.convnet} timed step(s)"})
 
+    vol_gib = a.size ** 3 * 4 / 2 ** 30
     if a.eval_steps > 0:
-        side_leg("eval", eval_leg)
-    if a.groupwise > 0:
-        side_leg("groupwise", groupwise_leg)
-    if a.sampler > 0 and rank == 0:
+        side_leg("eval", eval_leg, need_gib=a.pairs_per_gpu * 40 * vol_gib)
+    if a.groupwise > 0:       # the all-gather inside: entered by every rank or by none
+        side_leg("groupwise", groupwise_leg, need_gib=math.ceil(a.groupwise / world) * 60 * vol_gib)
+    if a.sampler > 0 and world == 1:
         side_leg("align_img_standalone", sampler_leg)
     if a.convnet > 0 and world == 1:
         side_leg("convnet", convnet_leg)
@@ -502,6 +610,11 @@ def main():
                 "global_pairs": a.pairs_per_gpu * world,
                 "rccl_ranks": rccl_ranks,
                 "backend": torch.distributed.get_backend() if world > 1 else None,
+                "launcher": ("bench.py self_launch" if os.environ.get("KEYMORPH_BENCH_SELF_LAUNCHED") == "1" else
+                             "torch.distributed.run / external") if world > 1 else None,
+                "rank_ms_per_step_min_max": [min(rank_ms), max(rank_ms)],
+                "allreduce_ms_per_step": allreduce_ms,
+                "allreduce_bytes": 4 * flat.numel,
                 "pair_seeds_rank0": [100 * rank + i for i in range(a.pairs_per_gpu)],
                 "pair_seed_rule": "rank r owns pairs 100 r + i, i < pairs-per-gpu (synthetic.make_pair seeds)",
                 "parity": "keypoints / grid / warped volume / MSE / Dice within 1e-4 of the reference arithmetic wherever the "
@@ -539,6 +652,17 @@ def main():
             vox_ratio = (a.size / 128) ** 3
             big = c.get("big") or {}
             measured = "seconds_per_pair" in big
+            if "ref" in big:            # oracle result at the metric's size vs the HIP path on the same pair and weights
+                from tests.oracle_at_size import compare_with_hip
+                try:
+                    par = compare_with_hip(big.pop("ref"), dev)
+                    per = par.pop("gradient_per_tensor")
+                    par["gradient_tensors_above_1e-3"] = {k: round(v, 6) for k, v in per.items() if v > 1e-3}
+                    par["what"] = ("HIP path (default arithmetic) vs the CPU oracle's forward and AUTOGRAD backward on the same "
+                                   f"{par['size']}^3 pair, seeded weights (23): max-abs differences; gradients relative L2")
+                    out["parity_at_size"] = par
+                except Exception as e:      # noqa: BLE001
+                    out["parity_at_size"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             # `value` is in the headline's units AT the headline's volume size and keypoint count: the measured
             # size^3 / 512-keypoint pair when the host could run it, else the 128^3 sample scaled by the voxel ratio
             value = 1.0 / big["seconds_per_pair"] if measured else 1.0 / (c["seconds_per_pair"] * vox_ratio)
@@ -549,6 +673,9 @@ def main():
                 "host_cores_available": c["host_cores"],
                 "cpu_model": c["cpu_model"],
                 "kind": "port",
+                "config": {"aligner": "affine (headline: tps_0)", "size": big.get("size", 128) if measured else 128,
+                           "keypoints": big.get("keypoints", 128) if measured else 128, "pairs_timed": 1 if measured else c["pairs"],
+                           "warm": not measured},
                 "comparable_to_headline": "same volume size and keypoint count, AFFINE aligner (512-keypoint TPS in "
                                           "training mode cannot run on the reference CPU path: 103 GB temporaries, "
                                           "BASELINE.md section 2; its chunked TPS costs more, so this flatters the CPU)",

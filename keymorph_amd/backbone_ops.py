@@ -689,6 +689,15 @@ class _UpCatConvGCR(torch.autograd.Function):
 
 def upcat_conv_gcr(skip, low, gamma, beta, weight, num_groups: int, dy_premasked: bool = False,
                    dskip_lazy: bool = False) -> Tensor:
+    if dskip_lazy:
+        # the hand-off is a contract between THIS operator's backward and pool_fork's: record it on pool_fork's node, so that
+        # its backward can tell "no tag because nothing was pending" from "the tag was lost on the way" (a hook, retain_grad
+        # or a second consumer of `skip` makes autograd re-wrap or sum the gradient, and the attribute does not survive)
+        node = skip.grad_fn
+        if node is not None and type(node).__name__ == "_PoolForkBackward":
+            node._kmh_expect_lazy = True
+        else:                          # not pool_fork's second output after all: apply GroupNorm's backward here
+            dskip_lazy = False
     y, ystats = _UpCatConvGCR.apply(skip, low, gamma, beta, weight, num_groups, dy_premasked, dskip_lazy)
     _tag_stats(y, ystats)
     return y
@@ -814,6 +823,13 @@ class _PoolFork(torch.autograd.Function):
         if lazy is not None and lazy[2] != dskip._version:
             raise RuntimeError("keymorph_amd: the skip gradient's pending GroupNorm backward lost its tag (a hook modified "
                                "the gradient?) -- set KEYMORPH_NO_LAZY_SKIP=1")
+        if lazy is None and dskip is not None and getattr(ctx, "_kmh_expect_lazy", False):
+            # the decoder handed over dxn with GroupNorm's backward PENDING, but what arrived is not that tensor (a hook or
+            # retain_grad on the skip tensor, or a second consumer whose gradient autograd added): summing it as a finished
+            # gradient would be silently wrong
+            raise RuntimeError("keymorph_amd: pool_fork expected the skip gradient with its GroupNorm backward pending, but the "
+                               "tensor that arrived carries no such tag (hook / retain_grad / second consumer of the skip "
+                               "tensor?) -- set KEYMORPH_NO_LAZY_SKIP=1 to apply GroupNorm's backward in the decoder")
         if lazy is not None:
             lib = _lib.load()
             c123, x, _ = lazy

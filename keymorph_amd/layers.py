@@ -30,3 +30,13 @@ class CenterOfMass2d(nn.Module):
     def forward(self, img):
         pts = ops.com3d(img.unsqueeze(2))[..., 1:]  # drop the degenerate z coordinate
         return pts.flip(-1) if self.indexing == "xy" else pts
+
+
+# keymorph/layers.py also defines ConvBlock (here: keymorph_amd/net.py, next to its only user; re-exported) and the LinearRegressor
+# keypoint layers, which are broken upstream (layers.py:6-27 read an undefined self.num_keypoints): names only.
+from ._absent import absent_class as _absent_class   # noqa: E402
+
+LinearRegressor2d = _absent_class("LinearRegressor2d", "keymorph/layers.py:6", nn.Module)
+LinearRegressor3d = _absent_class("LinearRegressor3d", "keymorph/layers.py:18", nn.Module)
+
+from .net import ConvBlock   # noqa: E402,F401

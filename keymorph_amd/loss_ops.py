@@ -183,3 +183,15 @@ class AvgJDStd(MultipleAvgGridMetric):
 class AvgJDLessThan0(MultipleAvgGridMetric):
     def forward(self, batch_of_grids):
         return super().forward(batch_of_grids, ["jdlessthan0"])["jdlessthan0"]
+
+
+# Host-side scipy / skimage metrics of the reference that are not on the path: the names exist so that
+# `import keymorph.loss_ops as loss_ops` users can reference them; calling / constructing raises NotImplementedError.
+from ._absent import absent_class as _absent_class, absent_function as _absent_function   # noqa: E402
+
+fast_dice = _absent_function("fast_dice", "keymorph/loss_ops.py:66")
+dice = _absent_function("dice", "keymorph/loss_ops.py:109")
+hausdorff_distance = _absent_function("hausdorff_distance", "keymorph/loss_ops.py:142")
+LC2 = _absent_class("LC2", "keymorph/loss_ops.py:250", torch.nn.Module)
+ImageLC2 = _absent_class("ImageLC2", "keymorph/loss_ops.py:305", torch.nn.Module)
+HausdorffPairwiseLoss = _absent_class("HausdorffPairwiseLoss", "keymorph/loss_ops.py:459", torch.nn.Module)

@@ -326,3 +326,11 @@ class KeyMorph(nn.Module):
             return self._make_aligner(align_type, points_m, points_f, tps_lmbda, None, (None, None, None, None))
         finally:
             self.align_keypoints_in_real_world_coords = saved
+
+
+# keymorph/model.py:533-640 also holds a brain-mask U-Net and its post-processing, unrelated to registration: names only.
+from ._absent import absent_class as _absent_class, absent_function as _absent_function   # noqa: E402
+
+Simple_Unet = _absent_class("Simple_Unet", "keymorph/model.py:533", nn.Module)
+simple_block = _absent_class("simple_block", "keymorph/model.py:598", nn.Module)
+clean_mask = _absent_function("clean_mask", "keymorph/model.py:622")

@@ -52,8 +52,8 @@ class FlatParams:
     Gradients are GATHERED, not accumulated: `zero_grad()` drops every `.grad` (no 64 MB memset), autograd then simply
     assigns each parameter's gradient tensor (no read-modify-write `add` launch per parameter: 36 of them per step for
     TruncatedUNet3D), and the first access to `.grad` afterwards copies them into the flat buffer with one multi-tensor
-    copy and re-points every `p.grad` at its slice -- so `flat.grad`, `p.grad` and gradient accumulation over several
-    backward passes behave as before."""
+    copy and re-points every `p.grad` at its slice (`gather()`; `allreduce_grads` and `FusedAdam.step` call it).  Gradient
+    accumulation over several backward passes works as long as `gather()` / `.grad` is read between them."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
@@ -77,25 +77,31 @@ class FlatParams:
         for p in self.params:
             p.grad = None
 
-    def _collect(self):
-        src, dst = [], []
+    def gather(self) -> torch.Tensor:
+        """Bring the flat gradient buffer up to date with every parameter's `.grad` (one multi-tensor copy, one multi-tensor
+        zero for parameters that received no gradient) and re-point each `p.grad` at its slice.  Returns the flat buffer.
+        CONTRACT: call this (or read `.grad`, which calls it) after EVERY backward pass; a reference to `flat.grad` or
+        `p.grad` taken before a backward pass is stale afterwards, and `_grad` must not be read directly."""
+        src, dst, zero = [], [], []
         for p, v in zip(self.params, self._views):
             g = p.grad
             if g is None:
-                v.zero_()
+                zero.append(v)
             elif g.data_ptr() != v.data_ptr():
                 src.append(g.detach().reshape(v.shape).to(v.dtype))
                 dst.append(v)
             p.grad = v
-        if dst:
-            with torch.no_grad():
+        with torch.no_grad():
+            if zero:
+                torch._foreach_zero_(zero)
+            if dst:
                 torch._foreach_copy_(dst, src)
+        return self._grad
 
     @property
     def grad(self) -> torch.Tensor:
-        """the flat gradient buffer, up to date with every parameter's `.grad`"""
-        self._collect()
-        return self._grad
+        """`gather()`: the flat gradient buffer, up to date with every parameter's `.grad` (has that side effect)"""
+        return self.gather()
 
     def broadcast(self, src: int = 0):
         if dist.is_initialized() and dist.get_world_size() > 1:
@@ -103,7 +109,7 @@ class FlatParams:
 
     def allreduce_grads(self) -> float:
         """sum over ranks (RCCL); returns the scale (1/world) the optimizer applies."""
-        g = self.grad
+        g = self.gather()
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
             return 1.0 / dist.get_world_size()
@@ -156,7 +162,7 @@ class FusedAdam:
     def step(self, grad_scale: float = 1.0):
         self.t += 1
         lib = _lib.load()
-        check(lib.kmh_adam_step(_p(self.flat.flat), _p(self.flat.grad), _p(self.m), _p(self.v), self.flat.numel,
+        check(lib.kmh_adam_step(_p(self.flat.flat), _p(self.flat.gather()), _p(self.m), _p(self.v), self.flat.numel,
                                 self.lr, self.betas[0], self.betas[1], self.eps, self.t, grad_scale, _stream()),
               "kmh_adam_step")
 

@@ -241,3 +241,14 @@ class TruncatedUNet3D(AbstractUNet):
                  layer_order="gcr", num_groups=8, num_levels=4, is_segmentation=True, conv_padding=1, **kwargs):
         super().__init__(in_channels, out_channels, final_sigmoid, f_maps, layer_order, num_groups, num_levels,
                          is_segmentation, conv_padding, num_truncated_layers)
+
+
+# Names the reference's scripts import beside UNet3D / TruncatedUNet3D (scripts/run.py:13, scripts/register.py:11) and that
+# are not on the 3-D registration path: they exist so that those import lines succeed, and raise when constructed.
+from .._absent import absent_class as _absent_class, absent_function as _absent_function   # noqa: E402
+
+UNet2D = _absent_class("UNet2D", "keymorph/unet3d/model.py:266", nn.Module)
+ResidualUNet3D = _absent_class("ResidualUNet3D", "keymorph/unet3d/model.py:192", nn.Module)
+ResidualUNetSE3D = _absent_class("ResidualUNetSE3D", "keymorph/unet3d/model.py:228", nn.Module)
+AbstractTruncatedUNet = AbstractUNet          # keymorph/unet3d/model.py:307: here one class takes `num_truncated_layers`
+get_model = _absent_function("get_model", "keymorph/unet3d/model.py:300")

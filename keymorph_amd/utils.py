@@ -190,3 +190,23 @@ def convert_flow_voxel2norm(flow, dim_sizes):
     for i, dim_size in enumerate(dim_sizes):
         flow[..., i] = 2 * (flow[..., i] + 0.5) / dim_size - 1
     return flow
+
+
+# Reference helpers outside the path (voxel-unit displacement fields of the baselines, SynthSeg label tables, 2-D sampling):
+# present as names, NotImplementedError when called.
+from ._absent import absent_function as _absent_function   # noqa: E402
+
+displacement2pytorchflow = _absent_function("displacement2pytorchflow", "keymorph/utils.py:24")
+pytorchflow2displacement = _absent_function("pytorchflow2displacement", "keymorph/utils.py:56")
+one_hot_eval_synthseg = _absent_function("one_hot_eval_synthseg", "keymorph/utils.py:164")
+uniform_voxel_grid = _absent_function("uniform_voxel_grid", "keymorph/utils.py:373")
+
+
+def sample_valid_coordinates_2d(x, num_points, point_space="norm"):
+    """keymorph/utils.py:117-137: the "xy" draw of `sample_valid_coordinates` for a (1, 1, H, W) image."""
+    return sample_valid_coordinates(x, num_points, 2, point_space=point_space, indexing="xy")
+
+
+def sample_valid_coordinates_3d(x, num_points, point_space="norm"):
+    """keymorph/utils.py:139-162: the "xy" draw of `sample_valid_coordinates` for a (1, 1, D, H, W) volume."""
+    return sample_valid_coordinates(x, num_points, 3, point_space=point_space, indexing="xy")

@@ -1013,6 +1013,39 @@ def test_skip_gradient_lazy_groupnorm_backward_in_pool_fork(monkeypatch):
         B.set_conv_mode(old)
 
 
+def test_lost_lazy_skip_tag_raises(monkeypatch):
+    """Round-3 advisor finding: a hook (or retain_grad, or a second consumer) on the skip tensor re-wraps the gradient, the
+    `pending GroupNorm backward` tag does not survive, and pool_fork's backward used to sum the RAW normalised-input
+    gradient as if it were finished.  The decoder now records the hand-off on pool_fork's node: a missing tag raises, and
+    KEYMORPH_NO_LAZY_SKIP=1 (GroupNorm's backward applied in the decoder) works with the same hook."""
+    from keymorph_amd import backbone_ops as B
+    from keymorph_amd.unet3d.model import UNet3D
+    torch.manual_seed(7)
+    net = UNet3D(1, 6, final_sigmoid=False, f_maps=32, layer_order="gcr", num_groups=8, num_levels=3,
+                 is_segmentation=False, conv_padding=1).to(DEV).train()
+    img = torch.rand(1, 1, 16, 16, 16, generator=gen(3)).to(DEV)
+    real = B.pool_fork
+
+    def hooked(x):
+        y, skip = real(x)
+        skip.register_hook(lambda g: g * 1.0)          # what a gradient-logging hook does: returns a new tensor
+        return y, skip
+
+    monkeypatch.setattr(B, "pool_fork", hooked)
+    monkeypatch.delenv("KEYMORPH_NO_LAZY_SKIP", raising=False)
+    with pytest.raises(RuntimeError, match="KEYMORPH_NO_LAZY_SKIP"):
+        net(img).sum().backward()
+    monkeypatch.setenv("KEYMORPH_NO_LAZY_SKIP", "1")
+    net.zero_grad(set_to_none=True)
+    net(img).sum().backward()
+    g_hook = {k: p.grad.clone() for k, p in net.named_parameters()}
+    monkeypatch.setattr(B, "pool_fork", real)
+    net.zero_grad(set_to_none=True)
+    net(img).sum().backward()
+    for k, p in net.named_parameters():
+        assert torch.equal(p.grad, g_hook[k]), k
+
+
 def test_pool_fork_backward_with_a_misaligned_skip_gradient_view():
     """kmh_maxpool3d_bwd's 16-byte kernel reads the second gradient as float4: a channel-slice view whose storage offset is
     not a multiple of 4 floats must take the scalar kernel (round-2 advisor finding) -- same result either way"""

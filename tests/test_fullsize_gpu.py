@@ -404,3 +404,56 @@ def test_bs2_tps0_forward_backward_vs_exact_fp32_mfma(world):
     assert abs(l16 - 0.5 * (singles[0] + singles[1])) <= 1e-4 * max(1.0, abs(l16))     # measured 1.2e-5 (conditioning)
     assert abs(l16 - l32) <= 1e-4 * max(1.0, abs(l32)), (l16, l32)
     assert whole <= 3e-2, whole
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the ORACLE at the metric's size.  Everything above compares the HIP path with itself (properties, arithmetic
+# modes); this runs oracle/keymorph_oracle.py's forward and autograd backward ONCE at 256^3 / 512 keypoints on the host
+# (~2 min, ~50 GB of RAM) and holds the HIP path to it: keymorph/model.py:142-289, utils.py:14-21, loss_ops.py:9-13.
+# ---------------------------------------------------------------------------------------------------------------------
+def _host_ram_gib():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return float(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+def test_fullsize_vs_oracle_256_affine():
+    """BASELINE configs[1] (256^3, 512 keypoints, affine, bs = 1), forward + backward, HIP vs the oracle on the same pair
+    and the same seeded weights: keypoints / matrix / grid / warped volume <= 1e-4 (north_star's bar), MSE <= 1e-6, the whole
+    parameter-gradient vector <= 2e-3 relative L2 against the oracle's AUTOGRAD (two fp32 implementations of 24 TFLOP;
+    ReLU kinks at rounding distance from zero are masked differently -- the per-tensor table is printed), and a forward-only
+    tps_1 leg: the oracle's TPS fit on the ORACLE's keypoints evaluated at 4096 sampled voxels vs the HIP grid."""
+    from tests.oracle_at_size import compare_with_hip, hip_model, oracle_pair
+    from oracle import keymorph_oracle as O
+    if _host_ram_gib() < 96:
+        pytest.skip("needs ~50 GB of host RAM for the oracle's 256^3 autograd graph")
+    ref = oracle_pair(SIZE, K, threads=32, tt="affine", seed=100, sd_seed=23)
+    par = compare_with_hip(ref, DEV)
+    per = par.pop("gradient_per_tensor")
+    print(f"256^3 affine vs oracle ({ref['seconds']:.0f} s on the host): " +
+          ", ".join(f"{k} {v:.2e}" for k, v in par.items() if isinstance(v, float)))
+    for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:8]:
+        print(f"   grad {k:60s} rel-L2 {v:.2e}")
+    assert par["keypoints"] <= 1e-4 and par["matrix"] <= 1e-4 and par["grid"] <= 1e-4 and par["warped"] <= 1e-4, par
+    assert par["mse"] <= 1e-6, par
+    assert par["gradient_rel_l2"] <= 2e-3, (par, per)
+    assert max(per.values()) <= 3e-2, per
+
+    # tps_1, forward only, same pair and weights: the oracle's fit on ITS keypoints at sampled voxels (4 sub-grids in the
+    # reference's eval mode change nothing per voxel: keypoint_aligners.py:365-433)
+    km = hip_model(ref["sd"], K, DEV).eval()
+    with torch.no_grad():
+        grid = km(ref["img_f"].to(DEV), ref["img_m"].to(DEV), transform_type="tps_1", return_aligned_points=False)["tps_1"]["grid"]
+    gen = torch.Generator().manual_seed(5)
+    idx = [torch.randint(0, SIZE, (4096,), generator=gen) for _ in range(3)]
+    g = O.base_grid((SIZE, SIZE, SIZE))[idx[0], idx[1], idx[2]].reshape(1, -1, 3)
+    lm = torch.full((1,), 1.0)
+    want = O.tps_transform_points(O.tps_fit(ref["points_f"], ref["points_m"], lm), ref["points_f"], g).flip(-1)[0]
+    got = grid[0][idx[0].to(DEV), idx[1].to(DEV), idx[2].to(DEV)].cpu()
+    err = float((got - want).abs().max())
+    print(f"256^3 tps_1 grid at 4096 sampled voxels vs oracle: {err:.2e}")
+    assert err <= 1e-4, err

@@ -354,3 +354,41 @@ def test_sample_valid_coordinates_golden():
         sample_valid_coordinates(x3, 2, 4)
     with pytest.raises(ValueError):
         sample_valid_coordinates(torch.zeros(1, 1, 3, 3, 3), 2, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py started the way the driver starts `--gpus 1` (plain `python bench.py --gpus N`, no torch.distributed.run) must
+# start N ranks by itself (replaces nn.DataParallel, scripts/run.py:390) -- or refuse; never print `n_gpus: 1` for N > 1.
+# KEYMORPH_BENCH_LAUNCH_CHECK=1 stops every rank after the process group's first collective (no HIP work on a CPU box);
+# the same launch WITH the HIP step runs on the GPU box in tests/test_multirank_gpu.py.
+# ---------------------------------------------------------------------------------------------------------------------
+def _bench(args, env_extra, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_self_launch_two_ranks_without_a_launcher():
+    r, line = _bench(["--gpus", "2", "--size", "24", "--keypoints", "16", "--steps", "1"],
+                     {"KEYMORPH_BENCH_LAUNCH_CHECK": "1", "KEYMORPH_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo" and line["self_launched"]
+    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1        # ONE line, from rank 0
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    r, line = _bench(["--gpus", "8"], {})
+    assert r.returncode == 2 and line is None
+    assert "needs 8 visible devices" in r.stderr
+
+
+def test_bench_rejects_world_size_mismatch():
+    r, line = _bench(["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0", "KEYMORPH_BENCH_LAUNCH_CHECK": "1"})
+    assert r.returncode != 0 and line is None and "WORLD_SIZE=4 but --gpus 2" in r.stderr
