@@ -142,7 +142,10 @@ def train_step(model, flat, opt, img_f, img_m, tt, seg_f=None, seg_m=None):
     if seg_f is None:
         loss, _img_a = ops.warp_mse(img_m, res["grid"], img_f)   # align_img + MSELoss, one pass
     else:
-        loss = loss_ops.DiceLoss()(utils.align_img(res["grid"], seg_m), seg_f)
+        if os.environ.get("KEYMORPH_BENCH_DICE_UNFUSED"):      # A/B: the three-launch route with the warped tensor stored
+            loss = loss_ops.DiceLoss()(utils.align_img(res["grid"], seg_m), seg_f)
+        else:
+            loss = loss_ops.warp_dice_loss(res["grid"], seg_m, seg_f)        # align_img + DiceLoss, nothing materialised
     loss.backward()
     scale = flat.allreduce_grads()
     opt.step(scale)
@@ -375,7 +378,8 @@ def main():
         extra.update({"dice_pairs_per_s": a.pairs_per_gpu * world / dt_d, "dice_ms_per_step": 1000 * dt_d,
                       "dice_loss": dice_loss,
                       "dice_config": f"loss_fn=dice: ({a.pairs_per_gpu},14,{a.size}^3) one-hot segmentations, align_img "
-                                     f"(bilinear) + DiceLoss fwd+bwd in place of warp+MSE, {a.dice} timed step(s)"})
+                                     f"(bilinear) + DiceLoss fwd+bwd as the fused loss_ops.warp_dice_loss (the warped "
+                                     f"segmentation is never stored) in place of warp+MSE, {a.dice} timed step(s)"})
         del seg_f, seg_m
     if a.also_f32 > 0 and a.conv != "f32":      # the same step on the exact fp32 MFMA, in the same driver run
         backbone_ops.set_conv_mode("f32")
@@ -656,8 +660,12 @@ def main():
                 from tests.oracle_at_size import compare_with_hip
                 try:
                     par = compare_with_hip(big.pop("ref"), dev)
-                    per = par.pop("gradient_per_tensor")
-                    par["gradient_tensors_above_1e-3"] = {k: round(v, 6) for k, v in per.items() if v > 1e-3}
+                    per, per_bb = par.pop("gradient_per_tensor"), par.pop("backbone_gradient_per_tensor")
+                    par["backbone_gradient_tensors_above_1e-3"] = {k: round(v, 6) for k, v in per_bb.items() if v > 1e-3}
+                    par["gradient_notes"] = ("gradient_rel_l2: loss.backward() end to end; backbone_gradient_rel_l2: the "
+                                             "backbone's backward alone, HIP and oracle on the SAME d(loss)/d(keypoints); "
+                                             "tail_rel_l2_*: d(loss)/d(keypoints) of each fp32 path vs the oracle's fp64 "
+                                             "tail (the ill-conditioned part: tests/oracle_at_size.py)")
                     par["what"] = ("HIP path (default arithmetic) vs the CPU oracle's forward and AUTOGRAD backward on the same "
                                    f"{par['size']}^3 pair, seeded weights (23): max-abs differences; gradients relative L2")
                     out["parity_at_size"] = par

@@ -64,6 +64,16 @@ int kmh_dice_sums(const float* pred, const float* target, int R, long long V, fl
 /* out[r,i] = ca[r]*t[r,i] + cb[r]*p[r,i] (Dice backward wrt pred) */
 int kmh_rows_axpby(const float* t, const float* p, const float* ca, const float* cb, int R, long long V,
                    float* out, void* stream);
+/* ---- a11 + a13 fused (scripts/train.py:146-164 with the Dice loss): align_img (keymorph/utils.py:14-21) followed by
+ *      the Dice sums (keymorph/loss_ops.py:28-52) WITHOUT storing the warped segmentation.
+ *      sums[(n*C + c)*3 + {0,1,2}] = {sum t p, sum p^2, sum t^2}, p = grid_sample(x, grid)[n,c], t = fixed[n,c].
+ *      -22 when the lane-contiguous sampler does not apply (W < 2, plane >= 2^31 voxels, C > 128). */
+int kmh_warp_dice_sums(const float* x, const float* grid, const float* fixed, float* sums, int N, int C, int D, int H,
+                       int W, int Do, int Ho, int Wo, void* ws, void* stream);
+/* its backward (autograd of keymorph/loss_ops.py:16-63 through keymorph/utils.py:14-21, one pass):
+ *      dgrid[n,v,:] = sum_c (ca[n*C+c] t + cb[n*C+c] p) * d p / d grid, with ca = -2 g / den, cb = 2 g num / den^2. */
+int kmh_warp_dice_bwd_grid(const float* x, const float* grid, const float* fixed, const float* ca, const float* cb,
+                           float* dgrid, int N, int C, int D, int H, int W, int Do, int Ho, int Wo, void* stream);
 /* hard Dice: onehot(argmax_c pred) over (N,C,V) -> out (N,C,V); first max wins like torch.argmax */
 int kmh_argmax_onehot(const float* pred, int N, int C, long long V, float* out, void* stream);
 /* keymorph/loss_ops.py:161-247 (_jacobian_determinant, jdstd, jdlessthan0): central differences with zero padding

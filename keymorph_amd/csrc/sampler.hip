@@ -445,6 +445,228 @@ __global__ __launch_bounds__(TPB) void sample_bwd_grid_lc_kernel(
   unstage_rows(dgrid + ((long long)n * ovox + vb) * 3, cnt, sg, tid);
 }
 
+// ----------------------------------------------------------------------------------------------
+// Fused align_img + soft DiceLoss (scripts/train.py:146-164 with loss_fn == "dice"; keymorph/utils.py:14-21,
+// keymorph/loss_ops.py:16-63) WITHOUT the warped segmentation ever being stored.  Dice couples every voxel of a
+// (sample, channel) row through its three sums, so the cotangent of the warp is only known after a full pass:
+//   pass A (warp_dice_sums_kernel)  per (n, c): sum t p, sum p^2, sum t^2 with p = warp(x)[n, c] recomputed on the fly;
+//   host: loss rows 1 - (2 I + 1) / (P + T + 1), and for the backward ca = -2 g / den, cb = 2 g num / den^2;
+//   pass B (warp_dice_grad_kernel)  d(loss)/d(grid) = sum_c (ca[n,c] t + cb[n,c] p) * d p / d grid, p recomputed again.
+// Per output voxel: A reads 12 + 8 C bytes, B reads 12 + 8 C and writes 12 -- the three-launch route (warp, Dice sums,
+// axpby, grid backward) moves 24 + 32 C.  Both kernels are persistent over 1024-voxel chunks (lane-contiguous like
+// sample_fwd_lc_kernel) and fetch the NEXT chunk's grid rows into registers before the current chunk's gathers.
+// ILP = voxels of a lane whose gathers are in flight together (PASSES / ILP sub-passes per chunk)
+constexpr int WD_MAXC = 128;
+
+struct GridRows { float4 a, b, c; };      // PASSES * 3 / 4 = 3 float4 per thread (named members: an array went to scratch)
+static_assert(PASSES * 3 / 4 == 3, "GridRows holds three float4 per thread");
+
+__device__ __forceinline__ bool rows_fast(const float* src, int cnt) {
+  return cnt == TPB * PASSES && ((reinterpret_cast<unsigned long long>(src) & 15) == 0);
+}
+__device__ __forceinline__ void fetch_rows(const float* __restrict__ src, bool fast, GridRows& g, int tid) {
+  if (fast) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    g.a = s4[tid]; g.b = s4[tid + TPB]; g.c = s4[tid + 2 * TPB];
+  }
+}
+__device__ __forceinline__ void commit_rows(const float* __restrict__ src, int cnt, bool fast, const GridRows& g, float* sg,
+                                            int tid) {
+  if (fast) {
+    float4* d4 = reinterpret_cast<float4*>(sg);
+    d4[tid] = g.a; d4[tid + TPB] = g.b; d4[tid + 2 * TPB] = g.c;
+  } else {
+    for (int e = tid; e < cnt * 3; e += TPB) sg[e] = src[e];
+  }
+}
+
+__device__ __forceinline__ void blend_grads(const float w[8], const Tap& t, float& dx, float& dy, float& dz) {
+  const float fx = t.fx, fy = t.fy, fz = t.fz;
+  const float ax = 1.f - fx, ay = 1.f - fy, az = 1.f - fz;
+  // d/dix, d/diy, d/diz of the trilinear blend (ATen grid_sampler_3d_backward), as sample_bwd_grid_lc_kernel
+  dx = -w[0] * (ay * az) + w[1] * (ay * az) - w[2] * (fy * az) + w[3] * (fy * az)
+       - w[4] * (ay * fz) + w[5] * (ay * fz) - w[6] * (fy * fz) + w[7] * (fy * fz);
+  dy = -w[0] * (ax * az) - w[1] * (fx * az) + w[2] * (ax * az) + w[3] * (fx * az)
+       - w[4] * (ax * fz) - w[5] * (fx * fz) + w[6] * (ax * fz) + w[7] * (fx * fz);
+  dz = -w[0] * (ax * ay) - w[1] * (fx * ay) - w[2] * (ax * fy) - w[3] * (fx * fy)
+       + w[4] * (ax * ay) + w[5] * (fx * ay) + w[6] * (ax * fy) + w[7] * (fx * fy);
+}
+
+// partial: (N, gridDim.x, C, 3) doubles
+template <int WD_ILP>
+__global__ __launch_bounds__(TPB) void warp_dice_sums_kernel(
+    const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ fixed,
+    double* __restrict__ partial, int C, int D, int H, int W, long long ovox, int nchunk) {
+  __shared__ __attribute__((aligned(16))) float sg[TPB * PASSES * 3];
+  __shared__ double racc[TPB / kWave][WD_MAXC][3];
+  const int n = blockIdx.y, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  for (int e = tid; e < (TPB / kWave) * WD_MAXC * 3; e += TPB) (&racc[0][0][0])[e] = 0.0;
+  const long long plane = (long long)D * H * W;
+  const float* gbase = grid + (long long)n * ovox * 3;
+  int chunk = blockIdx.x;
+  GridRows nxt = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  bool nfast = false;
+  if (chunk < nchunk) {
+    const long long vb = (long long)chunk * (TPB * PASSES);
+    const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
+    nfast = rows_fast(gbase + vb * 3, cnt);
+    fetch_rows(gbase + vb * 3, nfast, nxt, tid);
+  }
+#pragma unroll 1
+  for (; chunk < nchunk; chunk += gridDim.x) {
+    const long long vb = (long long)chunk * (TPB * PASSES);
+    const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
+    __syncthreads();                                  // the previous chunk's readers of sg are done
+    commit_rows(gbase + vb * 3, cnt, nfast, nxt, sg, tid);
+    __syncthreads();
+    {                                                 // the next chunk's rows: in flight under this chunk's gathers
+      const int c2 = chunk + gridDim.x;
+      if (c2 < nchunk) {
+        const long long vb2 = (long long)c2 * (TPB * PASSES);
+        const int cnt2 = ovox - vb2 < TPB * PASSES ? (int)(ovox - vb2) : TPB * PASSES;
+        nfast = rows_fast(gbase + vb2 * 3, cnt2);
+        fetch_rows(gbase + vb2 * 3, nfast, nxt, tid);
+      }
+    }
+#pragma unroll 1
+    for (int j0 = 0; j0 < PASSES; j0 += WD_ILP) {
+      Tap32 q[WD_ILP];
+      bool live[WD_ILP];
+#pragma unroll
+      for (int u = 0; u < WD_ILP; ++u) {
+        const int l = tid + (j0 + u) * TPB;
+        const Tap t = make_tap(sg[l * 3], sg[l * 3 + 1], sg[l * 3 + 2], D, H, W);
+        q[u] = make_tap32(t, D, H, W);
+        live[u] = l < cnt;
+        if (!live[u]) { q[u].r00 = q[u].r01 = q[u].r10 = q[u].r11 = 0; q[u].sel = false; }
+      }
+#pragma unroll 1
+      for (int c = 0; c < C; ++c) {
+        const float* p = x + ((long long)n * C + c) * plane;
+        const float* f = fixed + ((long long)n * C + c) * ovox + vb + j0 * TPB;
+        float v[WD_ILP][8], tv[WD_ILP];
+#pragma unroll
+        for (int u = 0; u < WD_ILP; ++u) {
+          gather8_pairs(p, q[u], v[u]);
+          tv[u] = live[u] ? f[tid + u * TPB] : 0.f;
+        }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < WD_ILP; ++u) {
+          Tap t;
+          t.fx = q[u].fx; t.fy = q[u].fy; t.fz = q[u].fz;
+          const float o = live[u] ? blend8(v[u], t) : 0.f;
+          s0 = fmaf(tv[u], o, s0); s1 = fmaf(o, o, s1); s2 = fmaf(tv[u], tv[u], s2);
+        }
+        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) { racc[wid][c][0] += (double)s0; racc[wid][c][1] += (double)s1; racc[wid][c][2] += (double)s2; }
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < C * 3; e += TPB) {
+    const int c = e / 3, k = e - c * 3;
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < TPB / kWave; ++w) s += racc[w][c][k];
+    partial[(((long long)n * gridDim.x + blockIdx.x) * C + c) * 3 + k] = s;
+  }
+}
+
+// partial (N, nb, C, 3) -> sums (N*C, 3) floats: one wave per (n, c, k), fixed order
+__global__ __launch_bounds__(TPB) void warp_dice_final_kernel(const double* __restrict__ partial, int nb, int C, int total,
+                                                              float* __restrict__ sums) {
+  const int e = blockIdx.x * (TPB / kWave) + (threadIdx.x >> 6);
+  if (e >= total) return;
+  const int lane = threadIdx.x & 63;
+  const int n = e / (C * 3), r = e - n * (C * 3);
+  const double* p = partial + (long long)n * nb * C * 3 + r;
+  double s = 0.0;
+  for (int b = lane; b < nb; b += kWave) s += p[(long long)b * C * 3];
+  s = wave_sum(s);
+  if (lane == 0) sums[e] = (float)s;
+}
+
+template <int WD_ILP>
+__global__ __launch_bounds__(TPB) void warp_dice_grad_kernel(
+    const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ fixed,
+    const float* __restrict__ ca, const float* __restrict__ cb, float* __restrict__ dgrid, int C, int D, int H, int W,
+    long long ovox, int nchunk) {
+  __shared__ __attribute__((aligned(16))) float sg[TPB * PASSES * 3];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const long long plane = (long long)D * H * W;
+  const float* gbase = grid + (long long)n * ovox * 3;
+  int chunk = blockIdx.x;
+  GridRows nxt = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  bool nfast = false;
+  if (chunk < nchunk) {
+    const long long vb = (long long)chunk * (TPB * PASSES);
+    const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
+    nfast = rows_fast(gbase + vb * 3, cnt);
+    fetch_rows(gbase + vb * 3, nfast, nxt, tid);
+  }
+#pragma unroll 1
+  for (; chunk < nchunk; chunk += gridDim.x) {
+    const long long vb = (long long)chunk * (TPB * PASSES);
+    const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
+    __syncthreads();                                  // the previous chunk's gradient rows have left sg
+    commit_rows(gbase + vb * 3, cnt, nfast, nxt, sg, tid);
+    __syncthreads();
+    {
+      const int c2 = chunk + gridDim.x;
+      if (c2 < nchunk) {
+        const long long vb2 = (long long)c2 * (TPB * PASSES);
+        const int cnt2 = ovox - vb2 < TPB * PASSES ? (int)(ovox - vb2) : TPB * PASSES;
+        nfast = rows_fast(gbase + vb2 * 3, cnt2);
+        fetch_rows(gbase + vb2 * 3, nfast, nxt, tid);
+      }
+    }
+#pragma unroll 1
+    for (int j0 = 0; j0 < PASSES; j0 += WD_ILP) {
+      Tap t[WD_ILP];
+      Tap32 q[WD_ILP];
+      bool live[WD_ILP];
+      float gx[WD_ILP], gy[WD_ILP], gz[WD_ILP];
+#pragma unroll
+      for (int u = 0; u < WD_ILP; ++u) {
+        const int l = tid + (j0 + u) * TPB;
+        t[u] = make_tap(sg[l * 3], sg[l * 3 + 1], sg[l * 3 + 2], D, H, W);
+        q[u] = make_tap32(t[u], D, H, W);
+        live[u] = l < cnt;
+        if (!live[u]) { q[u].r00 = q[u].r01 = q[u].r10 = q[u].r11 = 0; q[u].sel = false; }
+        gx[u] = gy[u] = gz[u] = 0.f;
+      }
+#pragma unroll 1
+      for (int c = 0; c < C; ++c) {
+        const float* p = x + ((long long)n * C + c) * plane;
+        const float* f = fixed + ((long long)n * C + c) * ovox + vb + j0 * TPB;
+        const float a = ca[n * C + c], b = cb[n * C + c];
+        float v[WD_ILP][8], tv[WD_ILP];
+#pragma unroll
+        for (int u = 0; u < WD_ILP; ++u) {
+          gather8_pairs(p, q[u], v[u]);
+          tv[u] = live[u] ? f[tid + u * TPB] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < WD_ILP; ++u) {
+          const float o = blend8(v[u], t[u]);
+          const float go = live[u] ? fmaf(a, tv[u], b * o) : 0.f;
+          float dx, dy, dz;
+          blend_grads(v[u], t[u], dx, dy, dz);
+          gx[u] = fmaf(dx, go, gx[u]); gy[u] = fmaf(dy, go, gy[u]); gz[u] = fmaf(dz, go, gz[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < WD_ILP; ++u) {              // each lane owns its rows of sg: coordinates in, gradient out
+        const int l = tid + (j0 + u) * TPB;
+        sg[l * 3] = gx[u] * t[u].mx; sg[l * 3 + 1] = gy[u] * t[u].my; sg[l * 3 + 2] = gz[u] * t[u].mz;
+      }
+    }
+    __syncthreads();
+    unstage_rows(dgrid + ((long long)n * ovox + vb) * 3, cnt, sg, tid);
+  }
+}
+
 // scatter-add backward wrt the sampled volume (not on the training hot path: the volumes are data;
 // used by augmentation-through-images and for completeness of align_img's autograd).
 __global__ __launch_bounds__(TPB) void sample_bwd_input_kernel(
@@ -779,6 +1001,52 @@ KMH_API int kmh_dice_sums(const float* pred, const float* target, int R, long lo
   if (nb < 1) nb = 1;
   dice_partial_kernel<<<dim3(nb, R), TPB, 0, s>>>(pred, target, V, (double*)ws);
   dice_finalize_kernel<<<R, TPB, 0, s>>>((const double*)ws, nb, sums);
+  return KMH_LAUNCH_CHECK();
+}
+
+/* Fused align_img + soft Dice sums: sums[(n*C + c)*3 + {0,1,2}] = {sum t p, sum p^2, sum t^2} over the output voxels, with
+ * p = grid_sample(x, grid)[n, c] (bilinear, border, align_corners = False) and t = fixed[n, c]; the warped tensor is never
+ * written.  Replaces keymorph/utils.py:14-21 followed by the three reductions of keymorph/loss_ops.py:28-52 (caller
+ * scripts/train.py:146-164).  ws: kmh_reduce_ws_bytes().  Returns KMH_EINVAL (-22) when the lane-contiguous kernel does
+ * not apply (W < 2, a plane of >= 2^31 voxels, C > 128): the caller then uses the separate entry points. */
+KMH_API int kmh_warp_dice_sums(const float* x, const float* grid, const float* fixed, float* sums, int N, int C, int D,
+                               int H, int W, int Do, int Ho, int Wo, void* ws, void* stream) {
+  if (N <= 0 || C <= 0 || C > WD_MAXC || !lane_contiguous_ok(D, H, W)) return -22;
+  const long long ovox = (long long)Do * Ho * Wo;
+  const int nchunk = ceil_div(ovox, (long long)TPB * PASSES);
+  long long nb = 65536 / ((long long)N * C);          // partial (N, nb, C, 3) doubles inside the reduction workspace
+  if (nb < 1) return -22;
+  if (nb > nchunk) nb = nchunk;
+  static const int capa = getenv("KMH_WD_BLOCKS") ? atoi(getenv("KMH_WD_BLOCKS")) : 2048;
+  if (nb > capa) nb = capa;
+  hipStream_t s = (hipStream_t)stream;
+  static const int ilp = getenv("KMH_WD_ILP_A") ? atoi(getenv("KMH_WD_ILP_A")) : 4;        // A/B switch (tools/bench_sampler.py)
+  if (ilp == 4)
+    warp_dice_sums_kernel<4><<<dim3((unsigned)nb, N), TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk);
+  else
+    warp_dice_sums_kernel<2><<<dim3((unsigned)nb, N), TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk);
+  const int total = N * C * 3;
+  warp_dice_final_kernel<<<ceil_div(total, TPB / kWave), TPB, 0, s>>>((const double*)ws, (int)nb, C, total, sums);
+  return KMH_LAUNCH_CHECK();
+}
+
+/* d/d(grid) of sum_{n,c} g[n,c] * DiceRow[n,c] given ca[n*C+c] = -2 g / den and cb[n*C+c] = 2 g num / den^2 (num = 2 I + 1,
+ * den = P + T + 1 from kmh_warp_dice_sums): dgrid[n, v, :] = sum_c (ca t + cb p) * d p / d grid, p recomputed from x.
+ * Autograd of keymorph/loss_ops.py:16-63 through keymorph/utils.py:14-21 in one pass. */
+KMH_API int kmh_warp_dice_bwd_grid(const float* x, const float* grid, const float* fixed, const float* ca, const float* cb,
+                                   float* dgrid, int N, int C, int D, int H, int W, int Do, int Ho, int Wo, void* stream) {
+  if (N <= 0 || C <= 0 || !lane_contiguous_ok(D, H, W)) return -22;
+  const long long ovox = (long long)Do * Ho * Wo;
+  const int nchunk = ceil_div(ovox, (long long)TPB * PASSES);
+  static const int cap = getenv("KMH_WD_BLOCKS") ? atoi(getenv("KMH_WD_BLOCKS")) : 4096;
+  static const int ilp = getenv("KMH_WD_ILP_B") ? atoi(getenv("KMH_WD_ILP_B")) : 2;
+  int nb = nchunk < cap ? nchunk : cap;
+  if (ilp == 4)
+    warp_dice_grad_kernel<4><<<dim3(nb, N), TPB, 0, (hipStream_t)stream>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox,
+                                                                           nchunk);
+  else
+    warp_dice_grad_kernel<2><<<dim3(nb, N), TPB, 0, (hipStream_t)stream>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox,
+                                                                           nchunk);
   return KMH_LAUNCH_CHECK();
 }
 

@@ -41,6 +41,20 @@ class DiceLoss(torch.nn.Module):
         return rows.mean()
 
 
+def warp_dice_loss(grid, seg_m, seg_f, ign_first_ch=False, return_regions=False):
+    """`DiceLoss(return_regions=...)(align_img(grid, seg_m), seg_f, ign_first_ch)` -- the Dice branch of
+    scripts/train.py:146-164 -- as ONE fused operator: the warped segmentation is never materialised (forward: one pass
+    over grid + both segmentations; backward: one more pass that writes d(loss)/d(grid)).  Falls back to exactly that
+    composition when the fused kernels do not apply (seg_m needing a gradient, 4-D inputs, > 128 channels)."""
+    if not ops.warp_dice_ok(seg_m, grid) or seg_f.requires_grad:
+        from .utils import align_img
+        return DiceLoss(return_regions=return_regions)(align_img(grid, seg_m), seg_f, ign_first_ch=ign_first_ch)
+    rows = ops.warp_dice_rows(seg_m, grid, seg_f)
+    if ign_first_ch:
+        rows = rows[:, 1:]
+    return rows.mean(0) if return_regions else rows.mean()
+
+
 # --------------------------------------------------------------------------
 # eval-only metrics on the GPU (keymorph/loss_ops.py:161-247; callers pairwise_register_eval.py:332-345)
 # --------------------------------------------------------------------------

@@ -236,6 +236,58 @@ def dice_rows(pred: Tensor, target: Tensor) -> Tensor:
     return _DiceRows.apply(pred, target)
 
 
+class _WarpDiceRows(torch.autograd.Function):
+    """Dice rows of align_img(grid, x) against `fixed` WITHOUT the warped tensor: one pass for the three sums per (n, c)
+    (kmh_warp_dice_sums), one pass for d/d(grid) (kmh_warp_dice_bwd_grid; the warp is recomputed, nothing is stored).
+    scripts/train.py:146-164 with loss_fn == "dice"; keymorph/utils.py:14-21 + keymorph/loss_ops.py:16-63."""
+
+    @staticmethod
+    def forward(ctx, x, grid, fixed):
+        lib = _lib.load()
+        x, grid, fixed = _prep(x), _prep(grid), _prep(fixed)
+        N, C, D, H, W = x.shape
+        _, Do, Ho, Wo, _ = grid.shape
+        assert fixed.shape == (N, C, Do, Ho, Wo), "the fixed segmentation must have the warped tensor's shape"
+        sums = torch.empty((N * C, 3), dtype=torch.float32, device=x.device)
+        if _lib.profiler.enabled:      # grid 12 B + C * (gathered volume 4 + fixed 4) per output voxel
+            _lib.profiler.meta = {"bytes": float(N * Do * Ho * Wo) * (12 + 8 * C)}
+        check(lib.kmh_warp_dice_sums(_p(x), _p(grid), _p(fixed), _p(sums), N, C, D, H, W, Do, Ho, Wo,
+                                     _p(_reduce_ws(x.device)), _stream()), "kmh_warp_dice_sums")
+        num = 2 * sums[:, 0] + 1
+        den = sums[:, 1] + sums[:, 2] + 1
+        ctx.save_for_backward(x, grid, fixed, num, den)
+        return (1 - num / den).view(N, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, grid, fixed, num, den = ctx.saved_tensors
+        N, C, D, H, W = x.shape
+        _, Do, Ho, Wo, _ = grid.shape
+        g = _prep(g).reshape(-1)
+        ca = (-2.0 * g / den).contiguous()
+        cb = (2.0 * g * num / (den * den)).contiguous()
+        dgrid = torch.empty_like(grid)
+        if _lib.profiler.enabled:      # the same reads + 12 B of grid gradient
+            _lib.profiler.meta = {"bytes": float(N * Do * Ho * Wo) * (24 + 8 * C)}
+        check(lib.kmh_warp_dice_bwd_grid(_p(x), _p(grid), _p(fixed), _p(ca), _p(cb), _p(dgrid), N, C, D, H, W, Do, Ho, Wo,
+                                         _stream()), "kmh_warp_dice_bwd_grid")
+        return None, dgrid, None
+
+
+def warp_dice_ok(x: Tensor, grid: Tensor) -> bool:
+    """does the fused warp + Dice pass apply?  (5-D, bilinear lane-contiguous sampler: W >= 2, < 2^31 voxels per channel
+    plane, <= 128 channels; the grid is the only input that needs a gradient)"""
+    return (x.dim() == 5 and grid.dim() == 5 and x.shape[4] >= 2 and x.shape[2] * x.shape[3] * x.shape[4] < 2 ** 31
+            and x.shape[1] <= 128 and not x.requires_grad)
+
+
+def warp_dice_rows(x: Tensor, grid: Tensor, fixed: Tensor) -> Tensor:
+    """-> (N, C) rows 1 - (2 sum t p + 1) / (sum p^2 + sum t^2 + 1) with p = align_img(grid, x), t = fixed; the gradient
+    flows to ``grid`` only."""
+    return _WarpDiceRows.apply(x, grid, fixed)
+
+
 def argmax_onehot(pred: Tensor) -> Tensor:
     lib = _lib.load()
     pred = _prep(pred)

@@ -4,12 +4,30 @@ the metric's volume size on the host cores, and the HIP path run on the same pai
 Used by tests/test_fullsize_gpu.py::test_fullsize_vs_oracle_256_affine and by bench.py's cpu_baseline leg (which times the
 oracle run and reports the comparison as `parity_at_size`); nothing in keymorph_amd/ imports this.  Restates, in the oracle's
 functional form, KeyMorph.forward + align_img + MSELoss + loss.backward() of scripts/train.py:129-176 for one pair
-(keymorph/model.py:142-289, keymorph/utils.py:14-21, keymorph/loss_ops.py:9-13)."""
+(keymorph/model.py:142-289, keymorph/utils.py:14-21, keymorph/loss_ops.py:9-13).
+
+The backward is taken in the two pieces the chain rule gives, so that they can be judged separately:
+  tail      (keypoints -> fit -> grid -> warp -> MSE): d(loss)/d(keypoints), 2 x K x 3 numbers.  Cheap, and badly conditioned
+            (a sum over 16.8 M voxels pushed through the inverse of a fit to clumped keypoints), so it is ALSO run in fp64
+            from the same fp32 keypoints: the "truth" both fp32 tails are measured against;
+  backbone  (image -> keypoints): the 24 TFLOP part.  The oracle's autograd runs it ONCE with its own fp32 tail gradient as
+            the cotangent -- arithmetically the same as loss.backward() end to end."""
 import time
 
 import torch
 
 from tests.util import seeded_state_dict, unet_shapes
+
+
+def _tail(O, pf, pm, img_f, img_m, tt):
+    """-> (register() result, warped, mse, d mse / d points_f, d mse / d points_m) in the dtype of the inputs"""
+    pf = pf.detach().clone().requires_grad_(True)
+    pm = pm.detach().clone().requires_grad_(True)
+    r = O.register(pf, pm, tt, img_f.shape[2:])
+    img_a = O.align_img(r["grid"], img_m)
+    mse = O.mse_loss(img_f, img_a)
+    dpf, dpm = torch.autograd.grad(mse, [pf, pm])
+    return r, img_a.detach(), mse.detach(), dpf, dpm
 
 
 def oracle_pair(size, keypoints, threads=32, tt="affine", seed=100, sd_seed=23):
@@ -27,15 +45,19 @@ def oracle_pair(size, keypoints, threads=32, tt="affine", seed=100, sd_seed=23):
     del g
     sd = {k: v.requires_grad_(True) for k, v in seeded_state_dict(unet_shapes(keypoints, 32, trunc=1), sd_seed).items()}
     t0 = time.time()
-    r = O.keymorph_forward(lambda x: O.unet3d_forward(sd, x, 4, 1, 8), img_f, img_m, tt)
+    pf = O.center_of_mass(O.unet3d_forward(sd, img_f, 4, 1, 8), "ij")           # keymorph/model.py:111-117
+    pm = O.center_of_mass(O.unet3d_forward(sd, img_m, 4, 1, 8), "ij")
+    r, img_a, mse, dpf, dpm = _tail(O, pf, pm, img_f, img_m, tt)
     t_fwd = time.time() - t0
-    img_a = O.align_img(r["grid"], img_m)
-    mse = O.mse_loss(img_f, img_a)
-    mse.backward()
+    torch.autograd.backward([pf, pm], [dpf, dpm])                               # == mse.backward() end to end
     dt = time.time() - t0
+    # the same tail in fp64 from the same (fp32) keypoints: what both fp32 tails are measured against
+    r64, _, mse64, dpf64, dpm64 = _tail(O, pf.double(), pm.double(), img_f.double(), img_m.double(), tt)
     out = {"img_f": img_f, "img_m": img_m, "sd": {k: v.detach() for k, v in sd.items()},
-           "grads": {k: v.grad.detach() for k, v in sd.items()}, "points_f": r["points_f"].detach(),
-           "points_m": r["points_m"].detach(), "grid": r["grid"].detach(), "img_a": img_a.detach(), "mse": float(mse.detach()),
+           "grads": {k: v.grad.detach() for k, v in sd.items()}, "points_f": pf.detach(), "points_m": pm.detach(),
+           "grid": r["grid"].detach(), "img_a": img_a, "mse": float(mse), "dpoints": torch.stack([dpf, dpm]),
+           "dpoints_fp64": torch.stack([dpf64, dpm64]), "mse_fp64": float(mse64), "grid_fp64_err": float(
+               (r["grid"].detach().double() - r64["grid"].detach()).abs().max()),
            "seconds": dt, "forward_seconds": t_fwd, "size": size, "keypoints": keypoints, "transform": tt}
     if "matrix" in r:
         out["matrix"] = r["matrix"].detach()
@@ -51,33 +73,58 @@ def hip_model(sd, keypoints, dev):
     return KeyMorph(net, keypoints, 3, max_train_keypoints=None).to(dev).train()
 
 
+def _grad_table(named_params, ref_grads):
+    per, num, den = {}, 0.0, 0.0
+    for k, p in named_params:
+        a, b = p.grad.detach().cpu().double(), ref_grads[k].double()
+        n, d = float((a - b).pow(2).sum()), float(b.pow(2).sum())
+        per[k] = (n / (d + 1e-300)) ** 0.5
+        num, den = num + n, den + d
+    return (num / den) ** 0.5, per
+
+
 def compare_with_hip(ref, dev="cuda"):
     """The HIP path (the bench's train step minus the optimizer) on `ref`'s pair and weights.  Returns max-abs differences of
-    keypoints / matrix / grid / warped volume, |MSE difference|, and relative-L2 gradient differences (whole vector, per tensor)."""
+    keypoints / matrix / grid / warped volume, |MSE difference|, and relative-L2 gradient differences:
+      gradient_rel_l2            end to end (HIP loss.backward() vs the oracle's), whole vector + per tensor;
+      backbone_gradient_rel_l2   the backbone's backward alone: HIP and oracle given the SAME cotangent d(loss)/d(keypoints)
+                                 (the oracle's fp32 one);
+      tail_rel_l2_{hip,oracle}   d(loss)/d(keypoints) of each against the fp64 tail."""
     from keymorph_amd import ops
     tt, K = ref["transform"], ref["keypoints"]
     km = hip_model(ref["sd"], K, dev)
     f, m = ref["img_f"].to(dev), ref["img_m"].to(dev)
     r = km(f, m, transform_type=tt, return_aligned_points=False)[tt]
+    got = {}
+    r["points_f"].register_hook(lambda g: got.__setitem__("f", g.detach().clone()))
+    r["points_m"].register_hook(lambda g: got.__setitem__("m", g.detach().clone()))
     loss, img_a = ops.warp_mse(m, r["grid"], f)
     loss.backward()
     mx = lambda a, b: float((a.detach().cpu().double() - b.double()).abs().max())      # noqa: E731
     out = {"size": ref["size"], "keypoints_n": K, "transform": tt,
            "keypoints": max(mx(r["points_f"], ref["points_f"]), mx(r["points_m"], ref["points_m"])),
            "grid": mx(r["grid"], ref["grid"]), "warped": mx(img_a, ref["img_a"]),
-           "mse": abs(float(loss.detach()) - ref["mse"]), "mse_oracle": ref["mse"]}
+           "mse": abs(float(loss.detach()) - ref["mse"]), "mse_oracle": ref["mse"],
+           "oracle_fp32_vs_fp64_grid": ref["grid_fp64_err"], "oracle_fp32_vs_fp64_mse": abs(ref["mse"] - ref["mse_fp64"])}
     if "matrix" in ref:
         out["matrix"] = mx(r["matrix"], ref["matrix"])
-    per = {}
-    num = den = 0.0
-    for k, p in km.backbone.named_parameters():
-        a, b = p.grad.detach().cpu().double(), ref["grads"][k].double()
-        n, d = float((a - b).pow(2).sum()), float(b.pow(2).sum())
-        per[k] = (n / (d + 1e-300)) ** 0.5
-        num, den = num + n, den + d
+    e2e, per = _grad_table(km.backbone.named_parameters(), ref["grads"])
     worst = max(per, key=per.get)
-    out.update({"gradient_rel_l2": (num / den) ** 0.5, "gradient_worst_tensor": worst, "gradient_worst_rel_l2": per[worst],
+    out.update({"gradient_rel_l2": e2e, "gradient_worst_tensor": worst, "gradient_worst_rel_l2": per[worst],
                 "gradient_per_tensor": per})
+    # the tails against fp64
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())                      # noqa: E731
+    dp_hip = torch.stack([got["f"], got["m"]]).cpu()
+    out["tail_rel_l2_hip"] = rel(dp_hip, ref["dpoints_fp64"])
+    out["tail_rel_l2_oracle"] = rel(ref["dpoints"], ref["dpoints_fp64"])
+    # the backbone's backward alone, on the oracle's cotangent
+    km.zero_grad(set_to_none=True)
+    pts = km.get_keypoints(torch.cat([f, m]))
+    torch.autograd.backward([pts], [ref["dpoints"].reshape(pts.shape).to(dev)])
+    bb, per_bb = _grad_table(km.backbone.named_parameters(), ref["grads"])
+    wb = max(per_bb, key=per_bb.get)
+    out.update({"backbone_gradient_rel_l2": bb, "backbone_gradient_worst_tensor": wb,
+                "backbone_gradient_worst_rel_l2": per_bb[wb], "backbone_gradient_per_tensor": per_bb})
     del km
     torch.cuda.empty_cache()
     return out

@@ -423,25 +423,32 @@ def _host_ram_gib():
 
 def test_fullsize_vs_oracle_256_affine():
     """BASELINE configs[1] (256^3, 512 keypoints, affine, bs = 1), forward + backward, HIP vs the oracle on the same pair
-    and the same seeded weights: keypoints / matrix / grid / warped volume <= 1e-4 (north_star's bar), MSE <= 1e-6, the whole
-    parameter-gradient vector <= 2e-3 relative L2 against the oracle's AUTOGRAD (two fp32 implementations of 24 TFLOP;
-    ReLU kinks at rounding distance from zero are masked differently -- the per-tensor table is printed), and a forward-only
-    tps_1 leg: the oracle's TPS fit on the ORACLE's keypoints evaluated at 4096 sampled voxels vs the HIP grid."""
+    and the same seeded weights.  Forward: keypoints / matrix / grid / warped volume <= 1e-4 (north_star's bar), MSE <= 1e-6.
+    Backward, against the oracle's AUTOGRAD, in the two pieces of the chain rule (tests/oracle_at_size.py):
+      * the BACKBONE's backward (24 TFLOP) on an identical cotangent d(loss)/d(keypoints): whole gradient vector <= 2e-3
+        relative L2, every tensor <= 1e-2 (two fp32 implementations; pre-activations at rounding distance from zero are
+        masked differently by each -- the per-tensor table is printed);
+      * the TAIL (keypoints -> affine fit -> grid -> warp -> MSE), whose gradient is 3072 numbers obtained by pushing a sum
+        over 16.8 M voxels through the inverse of a fit to clumped keypoints: both fp32 tails are measured against the fp64
+        tail, and ours must be no further from it than 1.25 x the oracle's own fp32 error (or 1e-4);
+      * end to end the difference is then bounded by what the two tails differ by: <= 2e-3 + 2 (tail_hip + tail_oracle).
+    Plus a forward-only tps_1 leg: the oracle's TPS fit on the ORACLE's keypoints at 4096 sampled voxels vs the HIP grid."""
     from tests.oracle_at_size import compare_with_hip, hip_model, oracle_pair
     from oracle import keymorph_oracle as O
     if _host_ram_gib() < 96:
         pytest.skip("needs ~50 GB of host RAM for the oracle's 256^3 autograd graph")
     ref = oracle_pair(SIZE, K, threads=32, tt="affine", seed=100, sd_seed=23)
     par = compare_with_hip(ref, DEV)
-    per = par.pop("gradient_per_tensor")
+    per, per_bb = par.pop("gradient_per_tensor"), par.pop("backbone_gradient_per_tensor")
     print(f"256^3 affine vs oracle ({ref['seconds']:.0f} s on the host): " +
           ", ".join(f"{k} {v:.2e}" for k, v in par.items() if isinstance(v, float)))
-    for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:8]:
-        print(f"   grad {k:60s} rel-L2 {v:.2e}")
+    for k, v in sorted(per_bb.items(), key=lambda kv: -kv[1])[:8]:
+        print(f"   backbone-only grad {k:60s} rel-L2 {v:.2e}   (end to end {per[k]:.2e})")
     assert par["keypoints"] <= 1e-4 and par["matrix"] <= 1e-4 and par["grid"] <= 1e-4 and par["warped"] <= 1e-4, par
     assert par["mse"] <= 1e-6, par
-    assert par["gradient_rel_l2"] <= 2e-3, (par, per)
-    assert max(per.values()) <= 3e-2, per
+    assert par["backbone_gradient_rel_l2"] <= 2e-3 and max(per_bb.values()) <= 1e-2, (par, per_bb)
+    assert par["tail_rel_l2_hip"] <= max(1e-4, 1.25 * par["tail_rel_l2_oracle"]), par
+    assert par["gradient_rel_l2"] <= 2e-3 + 2 * (par["tail_rel_l2_hip"] + par["tail_rel_l2_oracle"]), par
 
     # tps_1, forward only, same pair and weights: the oracle's fit on ITS keypoints at sampled voxels (4 sub-grids in the
     # reference's eval mode change nothing per voxel: keypoint_aligners.py:365-433)

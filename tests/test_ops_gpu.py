@@ -149,6 +149,55 @@ def test_dice_golden_and_grad():
     close(a_.grad, o["dice_soft_dpred"], 1e-8, 1e-4)
 
 
+@pytest.mark.parametrize("shape,C,N", [((9, 10, 11), 3, 2), ((16, 16, 16), 14, 1), ((5, 33, 70), 5, 2), ((24, 20, 50), 1, 1)])
+def test_fused_warp_dice_vs_oracle_and_unfused(shape, C, N):
+    """loss_ops.warp_dice_loss == DiceLoss()(align_img(grid, seg_m), seg_f) (scripts/train.py:146-164) in value and in
+    d/d(grid): against the oracle's autograd (keymorph/utils.py:14-21 + loss_ops.py:16-63 restated) and against this
+    package's unfused three-launch route; one-hot and soft segmentations, ragged sizes, grids that leave the volume
+    (border padding), the 1024-voxel chunk tail, ign_first_ch / return_regions."""
+    from keymorph_amd import loss_ops, utils
+    g = gen(61 + C)
+    D, H, W = shape
+    lab_m = torch.randint(0, C, (N, 1, D, H, W), generator=g)
+    lab_f = torch.randint(0, C, (N, 1, D, H, W), generator=g)
+    hot = lambda lab: torch.zeros(N, C, D, H, W).scatter_(1, lab, 1.0)       # noqa: E731
+    for soft in (False, True):
+        seg_m = hot(lab_m) if not soft else torch.rand(N, C, D, H, W, generator=g)
+        seg_f = hot(lab_f) if not soft else torch.rand(N, C, D, H, W, generator=g)
+        grid = (O.base_grid(shape).flip(-1)[None].repeat(N, 1, 1, 1, 1) * 1.08
+                + 0.05 * torch.randn(N, D, H, W, 3, generator=g))              # some samples fall outside [-1, 1]
+        for kw in ({}, {"ign_first_ch": True}, {"return_regions": True}):
+            if C == 1 and kw.get("ign_first_ch"):
+                continue
+            cot = torch.randn(C, generator=g) if kw.get("return_regions") else torch.tensor(1.0)
+            gr = grid.clone().requires_grad_(True)
+            ref = O.dice_loss(O.align_img(gr, seg_m), seg_f, **kw)
+            (ref * cot).sum().backward()
+            gh = grid.to(DEV).requires_grad_(True)
+            out = loss_ops.warp_dice_loss(gh, seg_m.to(DEV), seg_f.to(DEV), **kw)
+            (out * cot.to(DEV)).sum().backward()
+            gu = grid.to(DEV).requires_grad_(True)
+            unf = loss_ops.DiceLoss(return_regions=bool(kw.get("return_regions")))(
+                utils.align_img(gu, seg_m.to(DEV)), seg_f.to(DEV), ign_first_ch=bool(kw.get("ign_first_ch")))
+            (unf * cot.to(DEV)).sum().backward()
+            close(out, ref, 2e-6)
+            close(out, unf, 1e-6)
+            scale = float(gr.grad.abs().max())
+            close(gh.grad, gr.grad, 2e-5 * scale, 1e-4)
+            close(gh.grad, gu.grad, 2e-6 * scale, 1e-5)
+
+
+def test_fused_warp_dice_falls_back_when_the_moving_segmentation_needs_a_gradient():
+    from keymorph_amd import loss_ops, ops as kops
+    g = gen(9)
+    seg_m = torch.rand(1, 2, 6, 6, 6, generator=g).to(DEV).requires_grad_(True)
+    seg_f = torch.rand(1, 2, 6, 6, 6, generator=g).to(DEV)
+    grid = O.base_grid((6, 6, 6)).flip(-1)[None].to(DEV).requires_grad_(True)
+    assert not kops.warp_dice_ok(seg_m, grid)
+    loss_ops.warp_dice_loss(grid, seg_m, seg_f).backward()
+    assert seg_m.grad is not None and grid.grad is not None
+
+
 # ---------------------------------------------------------------- grids
 @pytest.mark.parametrize("shape", [(6, 7, 8), (16, 16, 16), (5, 9, 13)])
 def test_affine_grid(shape):
