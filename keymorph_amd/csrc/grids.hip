@@ -11,6 +11,7 @@
 // TPS backward is the transposed reduction: each lane owns KPT keypoints (6 accumulators
 // each), voxels + their incoming gradient are staged through LDS and broadcast.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -107,7 +108,10 @@ __global__ __launch_bounds__(192) void affine_grid_bwd_final(const double* __res
 
 // ---------------------------------------------------------------------------------------------
 // TPS forward on the implicit grid.  LDS: ctrl (T x float4: cz,cy,cx,0) + weights (T x float4).
-template <bool EXPLICIT_POINTS>
+// ROWQ (implicit grid with W % VPT == 0): the lane's VPT voxels are consecutive in x, so (cz - z)^2 + (cy - y)^2 + 1e-6 --
+// the inner two links of tps_d2's fma chain -- is ONE scalar per keypoint instead of VPT/2 packed evaluations: 4 plain
+// VALU replace 8 packed ones of the 22 per keypoint and voxel quad, bit-identical results (the chain's order is kept).
+template <bool EXPLICIT_POINTS, bool ROWQ = false>
 __global__ __launch_bounds__(TPB) void tps_eval_fwd_kernel(const float* __restrict__ theta,
                                                            const float* __restrict__ ctrl,
                                                            const float* __restrict__ pts,
@@ -150,15 +154,33 @@ __global__ __launch_bounds__(TPB) void tps_eval_fwd_kernel(const float* __restri
     qz[h] = kmh_f2{pz[2 * h], pz[2 * h + 1]}; qy[h] = kmh_f2{py[2 * h], py[2 * h + 1]}; qx[h] = kmh_f2{px[2 * h], px[2 * h + 1]};
     az2[h] = ay2[h] = ax2[h] = kmh_f2{0.f, 0.f};
   }
+  if constexpr (ROWQ && !EXPLICIT_POINTS) {
+    const float pz0 = pz[0], py0 = py[0];
 #pragma unroll 4
-  for (int t = 0; t < T; ++t) {
-    const float4 c = sc[t];
-    const float4 w = sw[t];
+    for (int t = 0; t < T; ++t) {
+      const float4 c = sc[t];
+      const float4 w = sw[t];
+      const float dzs = c.x - pz0, dys = c.y - py0;
+      const float zy = fmaf(dys, dys, fmaf(dzs, dzs, 1e-6f));      // tps_d2's chain up to its last link
+      const kmh_f2 zy2 = {zy, zy};
 #pragma unroll
-    for (int h = 0; h < VPT / 2; ++h) {
-      const kmh_f2 dz = c.x - qz[h], dy = c.y - qy[h], dx = c.z - qx[h];
-      const kmh_f2 u = tps_u2_from_d2(tps_d2(dz, dy, dx));
-      az2[h] += u * w.x; ay2[h] += u * w.y; ax2[h] += u * w.z;
+      for (int h = 0; h < VPT / 2; ++h) {
+        const kmh_f2 dx = c.z - qx[h];
+        const kmh_f2 u = tps_u2_from_d2(__builtin_elementwise_fma(dx, dx, zy2));
+        az2[h] += u * w.x; ay2[h] += u * w.y; ax2[h] += u * w.z;
+      }
+    }
+  } else {
+#pragma unroll 4
+    for (int t = 0; t < T; ++t) {
+      const float4 c = sc[t];
+      const float4 w = sw[t];
+#pragma unroll
+      for (int h = 0; h < VPT / 2; ++h) {
+        const kmh_f2 dz = c.x - qz[h], dy = c.y - qy[h], dx = c.z - qx[h];
+        const kmh_f2 u = tps_u2_from_d2(tps_d2(dz, dy, dx));
+        az2[h] += u * w.x; ay2[h] += u * w.y; ax2[h] += u * w.z;
+      }
     }
   }
 #pragma unroll
@@ -197,7 +219,9 @@ constexpr int BWD_TPB = 256;       // -> 512 keypoints per block pass
 constexpr int VSTAGE = 256;        // voxels staged per LDS refill (one per thread)
 constexpr int VCHUNK = 8192;       // voxels per block
 
-template <bool EXPLICIT_POINTS>
+// ROWS (implicit grid with W % VSTAGE == 0): a stage's 256 voxels are one piece of ONE grid row, so dz, dy and the inner
+// links of the distance chain are per-stage constants of the lane's keypoints, and sum f dz = dz sum f (same for dy).
+template <bool EXPLICIT_POINTS, bool ROWS = false>
 __global__ __launch_bounds__(BWD_TPB) void tps_eval_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ theta, const float* __restrict__ ctrl,
     const float* __restrict__ pts, float* __restrict__ partial /* (N, nchunk, T, 6) */, int T, int D,
@@ -246,6 +270,35 @@ __global__ __launch_bounds__(BWD_TPB) void tps_eval_bwd_kernel(
     sg[threadIdx.x] = g;  // zero gradient for out-of-range voxels => no contribution
     __syncthreads();
     const int cnt = (int)((vend - vs) < VSTAGE ? (vend - vs) : VSTAGE);
+    if constexpr (ROWS && !EXPLICIT_POINTS) {
+      const float4 p0 = sp[0];
+      const kmh_f2 dz = cz - p0.x, dy = cy - p0.y;
+      const kmh_f2 eps2 = {1e-6f, 1e-6f};
+      const kmh_f2 zy = __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, eps2));
+      kmh_f2 fs = {0.f, 0.f};
+#pragma unroll 2
+      for (int j = 0; j < cnt; ++j) {
+        const float px = sp[j].z;
+        const float4 gg = sg[j];
+        const kmh_f2 dx = cx - px;
+        const kmh_f2 d2 = __builtin_elementwise_fma(dx, dx, zy);      // == tps_d2(dz, dy, dx)
+        kmh_f2 rs, L;
+        rs.x = __builtin_amdgcn_rsqf(d2.x); rs.y = __builtin_amdgcn_rsqf(d2.y);
+        const kmh_f2 r = d2 * rs;
+        const kmh_f2 re = r + 1e-6f;
+        L.x = __builtin_amdgcn_logf(re.x); L.y = __builtin_amdgcn_logf(re.y);
+        const kmh_f2 u = d2 * L;
+        aw[0] += u * gg.x; aw[1] += u * gg.y; aw[2] += u * gg.z;
+        const kmh_f2 s = wz * gg.x + wy * gg.y + wx * gg.z;
+        const kmh_f2 tt = rs * 1e-6f;
+        const kmh_f2 f = s * __builtin_elementwise_fma(L, kmh_f2{2.f * 0.6931471805599453f, 2.f * 0.6931471805599453f},
+                                                       1.f - tt + tt * tt);
+        fs += f;
+        ac[2] += f * dx;
+      }
+      ac[0] += fs * dz; ac[1] += fs * dy;
+      continue;
+    }
 #pragma unroll 2
     for (int j = 0; j < cnt; ++j) {
       const float4 pp = sp[j];
@@ -451,8 +504,12 @@ KMH_API int kmh_tps_grid_fwd(const float* theta, const float* ctrl, float* out, 
   const long long nvox = (long long)D * H * W;
   const size_t lds = (size_t)T * 2 * sizeof(float4);
   if (lds > 64 * 1024) return -22;
-  tps_eval_fwd_kernel<false><<<dim3(ceil_div(nvox, (long long)TPB * VPT), N), TPB, lds, (hipStream_t)stream>>>(
-      theta, ctrl, nullptr, out, T, D, H, W, nvox);
+  static const bool no_rowq = getenv("KMH_TPS_NO_ROWQ") != nullptr;       // A/B switch (tools/prof_tps.py)
+  const dim3 g(ceil_div(nvox, (long long)TPB * VPT), N);
+  if (W % VPT == 0 && !no_rowq)
+    tps_eval_fwd_kernel<false, true><<<g, TPB, lds, (hipStream_t)stream>>>(theta, ctrl, nullptr, out, T, D, H, W, nvox);
+  else
+    tps_eval_fwd_kernel<false, false><<<g, TPB, lds, (hipStream_t)stream>>>(theta, ctrl, nullptr, out, T, D, H, W, nvox);
   return KMH_LAUNCH_CHECK();
 }
 
@@ -487,8 +544,13 @@ KMH_API int kmh_tps_grid_bwd(const float* dgrid, const float* theta, const float
   size_t off = ((size_t)N * nchunk * T * 6 * sizeof(float) + 255) & ~(size_t)255;
   double* affp = (double*)((char*)ws + off);
   float* dmat = (float*)((char*)affp + (size_t)N * AFF_BWD_BLOCKS * 12 * sizeof(double));
-  tps_eval_bwd_kernel<false><<<dim3(nchunk, ktiles, N), BWD_TPB, 0, s>>>(dgrid, theta, ctrl, nullptr, partial,
-                                                                       T, D, H, W, nvox, nchunk);
+  static const bool no_rowq = getenv("KMH_TPS_NO_ROWQ") != nullptr;
+  if (W % VSTAGE == 0 && !no_rowq)
+    tps_eval_bwd_kernel<false, true><<<dim3(nchunk, ktiles, N), BWD_TPB, 0, s>>>(dgrid, theta, ctrl, nullptr, partial,
+                                                                               T, D, H, W, nvox, nchunk);
+  else
+    tps_eval_bwd_kernel<false, false><<<dim3(nchunk, ktiles, N), BWD_TPB, 0, s>>>(dgrid, theta, ctrl, nullptr, partial,
+                                                                                T, D, H, W, nvox, nchunk);
   tps_bwd_final_kernel<<<dim3(ceil_div(T * 6, FIN_O), N), FIN_O * FIN_S, 0, s>>>(partial, nchunk, T, dtheta, dctrl, 0);
   const int nb = affine_bwd_blocks(nvox);
   affine_grid_bwd_partial<<<dim3(nb, N), TPB, 0, s>>>(dgrid, affp, D, H, W);

@@ -291,10 +291,12 @@ template <int MODE, bool FUSE_MSE, bool FUSE_GRAD = false>
 __global__ __launch_bounds__(TPB) void sample_fwd_lc_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ out,
     const float* __restrict__ fixed, double* __restrict__ partial, int C, int D, int H, int W, long long ovox,
-    float* __restrict__ dgrid = nullptr, float gcoef = 0.f /* 2 / (N C voxels) */) {
+    float* __restrict__ dgrid = nullptr, float gcoef = 0.f /* 2 / (N C voxels) */, int xcd = 1) {
   __shared__ __attribute__((aligned(16))) float sg[TPB * PASSES * 3];
   const int n = blockIdx.y, tid = threadIdx.x;
-  const long long vb = (long long)blockIdx.x * (TPB * PASSES);
+  // xcd: chunk of this block such that every XCD (= blockIdx.x % 8) sweeps ONE contiguous range of chunks: the chunks next
+  // to each other (and one z slice apart) gather from the same cache lines, which then sit in ONE L2 instead of 8
+  const long long vb = (long long)(xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * (TPB * PASSES);
   const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
   stage_rows(grid + ((long long)n * ovox + vb) * 3, cnt, sg, tid);
   __syncthreads();
@@ -387,11 +389,11 @@ __global__ __launch_bounds__(TPB) void sample_fwd_lc_kernel(
 
 __global__ __launch_bounds__(TPB) void sample_bwd_grid_lc_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ gout,
-    float* __restrict__ dgrid, int C, int D, int H, int W, long long ovox) {
+    float* __restrict__ dgrid, int C, int D, int H, int W, long long ovox, int xcd = 1) {
   __shared__ __attribute__((aligned(16))) float sg[TPB * PASSES * 3];
   constexpr int ILP = 2;                   // voxels whose 4 pair-gathers are in flight together (ILP = 1: 151 us, 2: 138 us)
   const int n = blockIdx.y, tid = threadIdx.x;
-  const long long vb = (long long)blockIdx.x * (TPB * PASSES);
+  const long long vb = (long long)(xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * (TPB * PASSES);
   const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
   stage_rows(grid + ((long long)n * ovox + vb) * 3, cnt, sg, tid);
   __syncthreads();
@@ -492,8 +494,71 @@ __device__ __forceinline__ void blend_grads(const float w[8], const Tap& t, floa
        + w[4] * (ax * ay) + w[5] * (fx * ay) + w[6] * (ax * fy) + w[7] * (fx * fy);
 }
 
+// Gathers go through BUFFER loads: the channel plane's base lives in a scalar descriptor that the channel loop advances
+// with two scalar adds, the per-voxel part is a 32-bit byte offset computed once per chunk -- no 64-bit VALU address
+// arithmetic and no address registers per load (flat loads cost this loop 2 VALU + 2 VGPRs per gather), and lanes past
+// the end of a chunk read zeros from the range check instead of needing clamped addresses.
+typedef unsigned kmh_u2 __attribute__((vector_size(8)));      // the builtin's own return type (an ext_vector_type
+                                                              // of the same size converts by SPLATTING element 0)
+struct TapB {
+  unsigned o00, o01, o10, o11;   // byte offsets of the four x-pairs inside one channel plane
+  bool sel;                      // x0 is the last column: the pair was loaded one to the left
+  float fx, fy, fz;
+};
+__device__ __forceinline__ TapB make_tapb(const Tap& t, int D, int H, int W) {
+  TapB q;
+  const int y1 = t.y0 + 1 < H ? t.y0 + 1 : t.y0, z1 = t.z0 + 1 < D ? t.z0 + 1 : t.z0;   // (fy = 0 / fz = 0 there)
+  q.sel = t.x0 > W - 2;
+  const int xb = q.sel ? W - 2 : t.x0;
+  q.o00 = 4u * (unsigned)((t.z0 * H + t.y0) * W + xb); q.o01 = 4u * (unsigned)((t.z0 * H + y1) * W + xb);
+  q.o10 = 4u * (unsigned)((z1 * H + t.y0) * W + xb);   q.o11 = 4u * (unsigned)((z1 * H + y1) * W + xb);
+  q.fx = t.fx; q.fy = t.fy; q.fz = t.fz;
+  return q;
+}
+__device__ __forceinline__ void pair_b(__amdgpu_buffer_rsrc_t r, unsigned off, bool sel, float& lo, float& hi) {
+  const kmh_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+  // (scalars first: __builtin_bit_cast applied directly to a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2)
+  const unsigned ua = v[0], ub = v[1];
+  const float a = __uint_as_float(ua), b = __uint_as_float(ub);
+  lo = sel ? b : a;
+  hi = sel ? 0.f : b;
+}
+__device__ __forceinline__ void gather8_b(__amdgpu_buffer_rsrc_t r, const TapB& q, float v[8]) {
+  pair_b(r, q.o00, q.sel, v[0], v[1]);
+  pair_b(r, q.o01, q.sel, v[2], v[3]);
+  pair_b(r, q.o10, q.sel, v[4], v[5]);
+  pair_b(r, q.o11, q.sel, v[6], v[7]);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float blend8f(const float v[8], float fx, float fy, float fz) {
+  Tap t;
+  t.fx = fx; t.fy = fy; t.fz = fz;
+  return blend8(v, t);
+}
+
+// XCD-aware walk over a sample's chunks for a PERSISTENT launch (gridDim.x a multiple of 8, ideally no more blocks than
+// are resident at once).  A rotated / sheared sampling grid makes a 4-row chunk touch ~50 source rows, and the chunks next
+// to it (and the next z slice) touch the same cache lines; dealt round-robin, neighbouring chunks land on 8 different XCDs
+// and every one of their L2s fetches its own copy (measured on the strided version: 3.4x the algorithmic bytes through
+// FETCH_SIZE, L2 hit rate 37 %).  Here XCD k (= blockIdx.x % 8: observed dispatch order, used for speed only -- any
+// placement is correct) owns ONE contiguous range of chunks and its resident blocks sweep it side by side.
+struct ChunkWalk { int cur, end, step; };
+__device__ __forceinline__ ChunkWalk chunk_walk(int b, int nb, int nchunk) {
+  const int NX = nb < 8 ? nb : 8;            // fewer than 8 blocks: as many ranges as blocks (every range needs an owner)
+  const int xcd = b % NX, idx = b / NX;
+  const int q = nchunk / NX, r = nchunk % NX;
+  ChunkWalk w;
+  const int lo = xcd * q + (xcd < r ? xcd : r);
+  w.end = lo + q + (xcd < r ? 1 : 0);
+  w.step = (nb - xcd + NX - 1) / NX;          // blocks of this launch row that sit on this XCD
+  w.cur = lo + idx;
+  return w;
+}
+
 // partial: (N, gridDim.x, C, 3) doubles
-template <int WD_ILP>
+template <int WD_ILP, int UC = 1>
 __global__ __launch_bounds__(TPB) void warp_dice_sums_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ fixed,
     double* __restrict__ partial, int C, int D, int H, int W, long long ovox, int nchunk) {
@@ -502,26 +567,28 @@ __global__ __launch_bounds__(TPB) void warp_dice_sums_kernel(
   const int n = blockIdx.y, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   for (int e = tid; e < (TPB / kWave) * WD_MAXC * 3; e += TPB) (&racc[0][0][0])[e] = 0.0;
   const long long plane = (long long)D * H * W;
+  const unsigned plane_bytes = (unsigned)(plane * 4);
   const float* gbase = grid + (long long)n * ovox * 3;
-  int chunk = blockIdx.x;
+  const ChunkWalk cw = chunk_walk(blockIdx.x, gridDim.x, nchunk);
+  int chunk = cw.cur;
   GridRows nxt = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   bool nfast = false;
-  if (chunk < nchunk) {
+  if (chunk < cw.end) {
     const long long vb = (long long)chunk * (TPB * PASSES);
     const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
     nfast = rows_fast(gbase + vb * 3, cnt);
     fetch_rows(gbase + vb * 3, nfast, nxt, tid);
   }
 #pragma unroll 1
-  for (; chunk < nchunk; chunk += gridDim.x) {
+  for (; chunk < cw.end; chunk += cw.step) {
     const long long vb = (long long)chunk * (TPB * PASSES);
     const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
     __syncthreads();                                  // the previous chunk's readers of sg are done
     commit_rows(gbase + vb * 3, cnt, nfast, nxt, sg, tid);
     __syncthreads();
     {                                                 // the next chunk's rows: in flight under this chunk's gathers
-      const int c2 = chunk + gridDim.x;
-      if (c2 < nchunk) {
+      const int c2 = chunk + cw.step;
+      if (c2 < cw.end) {
         const long long vb2 = (long long)c2 * (TPB * PASSES);
         const int cnt2 = ovox - vb2 < TPB * PASSES ? (int)(ovox - vb2) : TPB * PASSES;
         nfast = rows_fast(gbase + vb2 * 3, cnt2);
@@ -530,32 +597,29 @@ __global__ __launch_bounds__(TPB) void warp_dice_sums_kernel(
     }
 #pragma unroll 1
     for (int j0 = 0; j0 < PASSES; j0 += WD_ILP) {
-      Tap32 q[WD_ILP];
-      bool live[WD_ILP];
+      TapB q[WD_ILP];
 #pragma unroll
       for (int u = 0; u < WD_ILP; ++u) {
         const int l = tid + (j0 + u) * TPB;
-        const Tap t = make_tap(sg[l * 3], sg[l * 3 + 1], sg[l * 3 + 2], D, H, W);
-        q[u] = make_tap32(t, D, H, W);
-        live[u] = l < cnt;
-        if (!live[u]) { q[u].r00 = q[u].r01 = q[u].r10 = q[u].r11 = 0; q[u].sel = false; }
+        q[u] = make_tapb(make_tap(sg[l * 3], sg[l * 3 + 1], sg[l * 3 + 2], D, H, W), D, H, W);
+        if (l >= cnt) q[u].o00 = q[u].o01 = q[u].o10 = q[u].o11 = plane_bytes;      // past the range check: reads 0
       }
-#pragma unroll 1
+      const int left = cnt - j0 * TPB;                 // voxels of the chunk from this sub-pass on (may be <= 0)
+      const unsigned fbytes = left > 0 ? 4u * (unsigned)left : 0u;
+#pragma unroll UC
       for (int c = 0; c < C; ++c) {
-        const float* p = x + ((long long)n * C + c) * plane;
-        const float* f = fixed + ((long long)n * C + c) * ovox + vb + j0 * TPB;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + ((long long)n * C + c) * plane, plane_bytes);
+        const __amdgpu_buffer_rsrc_t rf = make_rsrc(fixed + ((long long)n * C + c) * ovox + vb + j0 * TPB, fbytes);
         float v[WD_ILP][8], tv[WD_ILP];
 #pragma unroll
         for (int u = 0; u < WD_ILP; ++u) {
-          gather8_pairs(p, q[u], v[u]);
-          tv[u] = live[u] ? f[tid + u * TPB] : 0.f;
+          gather8_b(rx, q[u], v[u]);
+          tv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, 4 * (tid + u * TPB), 0, 0));
         }
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int u = 0; u < WD_ILP; ++u) {
-          Tap t;
-          t.fx = q[u].fx; t.fy = q[u].fy; t.fz = q[u].fz;
-          const float o = live[u] ? blend8(v[u], t) : 0.f;
+          const float o = blend8f(v[u], q[u].fx, q[u].fy, q[u].fz);      // 0 for lanes past the chunk (all corners read 0)
           s0 = fmaf(tv[u], o, s0); s1 = fmaf(o, o, s1); s2 = fmaf(tv[u], tv[u], s2);
         }
         s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
@@ -587,7 +651,7 @@ __global__ __launch_bounds__(TPB) void warp_dice_final_kernel(const double* __re
   if (lane == 0) sums[e] = (float)s;
 }
 
-template <int WD_ILP>
+template <int WD_ILP, int UC = 1>
 __global__ __launch_bounds__(TPB) void warp_dice_grad_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ fixed,
     const float* __restrict__ ca, const float* __restrict__ cb, float* __restrict__ dgrid, int C, int D, int H, int W,
@@ -595,26 +659,28 @@ __global__ __launch_bounds__(TPB) void warp_dice_grad_kernel(
   __shared__ __attribute__((aligned(16))) float sg[TPB * PASSES * 3];
   const int n = blockIdx.y, tid = threadIdx.x;
   const long long plane = (long long)D * H * W;
+  const unsigned plane_bytes = (unsigned)(plane * 4);
   const float* gbase = grid + (long long)n * ovox * 3;
-  int chunk = blockIdx.x;
+  const ChunkWalk cw = chunk_walk(blockIdx.x, gridDim.x, nchunk);
+  int chunk = cw.cur;
   GridRows nxt = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   bool nfast = false;
-  if (chunk < nchunk) {
+  if (chunk < cw.end) {
     const long long vb = (long long)chunk * (TPB * PASSES);
     const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
     nfast = rows_fast(gbase + vb * 3, cnt);
     fetch_rows(gbase + vb * 3, nfast, nxt, tid);
   }
 #pragma unroll 1
-  for (; chunk < nchunk; chunk += gridDim.x) {
+  for (; chunk < cw.end; chunk += cw.step) {
     const long long vb = (long long)chunk * (TPB * PASSES);
     const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
     __syncthreads();                                  // the previous chunk's gradient rows have left sg
     commit_rows(gbase + vb * 3, cnt, nfast, nxt, sg, tid);
     __syncthreads();
     {
-      const int c2 = chunk + gridDim.x;
-      if (c2 < nchunk) {
+      const int c2 = chunk + cw.step;
+      if (c2 < cw.end) {
         const long long vb2 = (long long)c2 * (TPB * PASSES);
         const int cnt2 = ovox - vb2 < TPB * PASSES ? (int)(ovox - vb2) : TPB * PASSES;
         nfast = rows_fast(gbase + vb2 * 3, cnt2);
@@ -623,43 +689,45 @@ __global__ __launch_bounds__(TPB) void warp_dice_grad_kernel(
     }
 #pragma unroll 1
     for (int j0 = 0; j0 < PASSES; j0 += WD_ILP) {
-      Tap t[WD_ILP];
-      Tap32 q[WD_ILP];
-      bool live[WD_ILP];
+      TapB q[WD_ILP];
       float gx[WD_ILP], gy[WD_ILP], gz[WD_ILP];
 #pragma unroll
       for (int u = 0; u < WD_ILP; ++u) {
         const int l = tid + (j0 + u) * TPB;
-        t[u] = make_tap(sg[l * 3], sg[l * 3 + 1], sg[l * 3 + 2], D, H, W);
-        q[u] = make_tap32(t[u], D, H, W);
-        live[u] = l < cnt;
-        if (!live[u]) { q[u].r00 = q[u].r01 = q[u].r10 = q[u].r11 = 0; q[u].sel = false; }
+        q[u] = make_tapb(make_tap(sg[l * 3], sg[l * 3 + 1], sg[l * 3 + 2], D, H, W), D, H, W);
+        if (l >= cnt) q[u].o00 = q[u].o01 = q[u].o10 = q[u].o11 = plane_bytes;      // reads 0: no contribution
         gx[u] = gy[u] = gz[u] = 0.f;
       }
-#pragma unroll 1
+      const int left = cnt - j0 * TPB;
+      const unsigned fbytes = left > 0 ? 4u * (unsigned)left : 0u;
+#pragma unroll UC
       for (int c = 0; c < C; ++c) {
-        const float* p = x + ((long long)n * C + c) * plane;
-        const float* f = fixed + ((long long)n * C + c) * ovox + vb + j0 * TPB;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + ((long long)n * C + c) * plane, plane_bytes);
+        const __amdgpu_buffer_rsrc_t rf = make_rsrc(fixed + ((long long)n * C + c) * ovox + vb + j0 * TPB, fbytes);
         const float a = ca[n * C + c], b = cb[n * C + c];
         float v[WD_ILP][8], tv[WD_ILP];
 #pragma unroll
         for (int u = 0; u < WD_ILP; ++u) {
-          gather8_pairs(p, q[u], v[u]);
-          tv[u] = live[u] ? f[tid + u * TPB] : 0.f;
+          gather8_b(rx, q[u], v[u]);
+          tv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, 4 * (tid + u * TPB), 0, 0));
         }
 #pragma unroll
         for (int u = 0; u < WD_ILP; ++u) {
-          const float o = blend8(v[u], t[u]);
-          const float go = live[u] ? fmaf(a, tv[u], b * o) : 0.f;
+          Tap t;
+          t.fx = q[u].fx; t.fy = q[u].fy; t.fz = q[u].fz;
+          const float o = blend8(v[u], t);
+          const float go = fmaf(a, tv[u], b * o);          // 0 past the chunk: tv and every corner read 0
           float dx, dy, dz;
-          blend_grads(v[u], t[u], dx, dy, dz);
+          blend_grads(v[u], t, dx, dy, dz);
           gx[u] = fmaf(dx, go, gx[u]); gy[u] = fmaf(dy, go, gy[u]); gz[u] = fmaf(dz, go, gz[u]);
         }
       }
 #pragma unroll
       for (int u = 0; u < WD_ILP; ++u) {              // each lane owns its rows of sg: coordinates in, gradient out
         const int l = tid + (j0 + u) * TPB;
-        sg[l * 3] = gx[u] * t[u].mx; sg[l * 3 + 1] = gy[u] * t[u].my; sg[l * 3 + 2] = gz[u] * t[u].mz;
+        float mx, my, mz;                              // d(ix)/d(gx) incl. the clamp mask, from the coordinates still in sg
+        unnorm_clip(sg[l * 3], W, mx); unnorm_clip(sg[l * 3 + 1], H, my); unnorm_clip(sg[l * 3 + 2], D, mz);
+        sg[l * 3] = gx[u] * mx; sg[l * 3 + 1] = gy[u] * my; sg[l * 3 + 2] = gz[u] * mz;
       }
     }
     __syncthreads();
@@ -866,6 +934,10 @@ __global__ __launch_bounds__(TPB) void jacdet_final_kernel(const double* __restr
   }
 }
 
+static int sampler_xcd() {      // A/B switch: KMH_SAMPLER_XCD=0 deals the chunks round-robin over the XCDs again
+  static const int v = getenv("KMH_SAMPLER_XCD") ? atoi(getenv("KMH_SAMPLER_XCD")) : 1;
+  return v;
+}
 static bool lane_contiguous_ok(int D, int H, int W) {
   static const bool force_old = getenv("KMH_SAMPLER_OLD") != nullptr;   // A/B switch for tools/bench_sampler.py
   return !force_old && W >= 2 && (long long)D * H * W < (1ll << 31);
@@ -883,9 +955,9 @@ KMH_API int kmh_grid_sample3d_fwd(const float* x, const float* grid, float* out,
   hipStream_t s = (hipStream_t)stream;
   if (lane_contiguous_ok(D, H, W)) {
     if (mode == 0)
-      sample_fwd_lc_kernel<0, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox);
+      sample_fwd_lc_kernel<0, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox, nullptr, 0.f, sampler_xcd());
     else
-      sample_fwd_lc_kernel<1, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox);
+      sample_fwd_lc_kernel<1, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox, nullptr, 0.f, sampler_xcd());
   } else if (mode == 0) {
     sample_fwd_kernel<0, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox);
   } else {
@@ -902,7 +974,7 @@ KMH_API int kmh_warp_mse_fwd(const float* x, const float* grid, const float* fix
   if ((long long)g.x * g.y > 65536 * 3) return -22;
   hipStream_t s = (hipStream_t)stream;
   if (lane_contiguous_ok(D, H, W)) {
-    sample_fwd_lc_kernel<0, true><<<g, TPB, 0, s>>>(x, grid, out, fixed, (double*)ws, C, D, H, W, ovox);
+    sample_fwd_lc_kernel<0, true><<<g, TPB, 0, s>>>(x, grid, out, fixed, (double*)ws, C, D, H, W, ovox, nullptr, 0.f, sampler_xcd());
   } else {
     sample_fwd_kernel<0, true><<<g, TPB, 0, s>>>(x, grid, out, fixed, (double*)ws, C, D, H, W, ovox);
   }
@@ -938,7 +1010,7 @@ KMH_API int kmh_warp_mse_fwd_grad(const float* x, const float* grid, const float
   hipStream_t s = (hipStream_t)stream;
   const double cnt = (double)N * C * (double)ovox;
   sample_fwd_lc_kernel<0, true, true><<<g, TPB, 0, s>>>(x, grid, out, fixed, (double*)ws, C, D, H, W, ovox, dgrid,
-                                                        (float)(2.0 / cnt));
+                                                        (float)(2.0 / cnt), sampler_xcd());
   finalize_mean_kernel<<<1, TPB, 0, s>>>((const double*)ws, (int)(g.x * g.y), 1.0 / cnt, out_loss);
   return KMH_LAUNCH_CHECK();
 }
@@ -958,7 +1030,7 @@ KMH_API int kmh_grid_sample3d_bwd_grid(const float* x, const float* grid, const 
   const long long ovox = (long long)Do * Ho * Wo;
   dim3 g(ceil_div(ovox, (long long)TPB * VPT), N);
   if (lane_contiguous_ok(D, H, W))
-    sample_bwd_grid_lc_kernel<<<g, TPB, 0, (hipStream_t)stream>>>(x, grid, gout, dgrid, C, D, H, W, ovox);
+    sample_bwd_grid_lc_kernel<<<g, TPB, 0, (hipStream_t)stream>>>(x, grid, gout, dgrid, C, D, H, W, ovox, sampler_xcd());
   else
     sample_bwd_grid_kernel<<<g, TPB, 0, (hipStream_t)stream>>>(x, grid, gout, dgrid, C, D, H, W, ovox);
   return KMH_LAUNCH_CHECK();
@@ -1011,20 +1083,27 @@ KMH_API int kmh_dice_sums(const float* pred, const float* target, int R, long lo
  * not apply (W < 2, a plane of >= 2^31 voxels, C > 128): the caller then uses the separate entry points. */
 KMH_API int kmh_warp_dice_sums(const float* x, const float* grid, const float* fixed, float* sums, int N, int C, int D,
                                int H, int W, int Do, int Ho, int Wo, void* ws, void* stream) {
-  if (N <= 0 || C <= 0 || C > WD_MAXC || !lane_contiguous_ok(D, H, W)) return -22;
+  if (N <= 0 || C <= 0 || C > WD_MAXC || !lane_contiguous_ok(D, H, W) || (long long)D * H * W >= (1ll << 30)) return -22;
   const long long ovox = (long long)Do * Ho * Wo;
   const int nchunk = ceil_div(ovox, (long long)TPB * PASSES);
   long long nb = 65536 / ((long long)N * C);          // partial (N, nb, C, 3) doubles inside the reduction workspace
   if (nb < 1) return -22;
   if (nb > nchunk) nb = nchunk;
-  static const int capa = getenv("KMH_WD_BLOCKS") ? atoi(getenv("KMH_WD_BLOCKS")) : 2048;
-  if (nb > capa) nb = capa;
+  static const int capa = getenv("KMH_WD_BLOCKS") ? atoi(getenv("KMH_WD_BLOCKS")) : 768;   // ~ resident blocks of the chip
+  const int per_n = (capa / N) & ~7;                 // a multiple of 8 per sample row: blockIdx.x % 8 is the XCD
+  if (nb > per_n) nb = per_n < 8 ? 8 : per_n;
   hipStream_t s = (hipStream_t)stream;
   static const int ilp = getenv("KMH_WD_ILP_A") ? atoi(getenv("KMH_WD_ILP_A")) : 4;        // A/B switch (tools/bench_sampler.py)
-  if (ilp == 4)
-    warp_dice_sums_kernel<4><<<dim3((unsigned)nb, N), TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk);
+  static const int uc = getenv("KMH_WD_UC") ? atoi(getenv("KMH_WD_UC")) : 1;
+  const dim3 g((unsigned)nb, N);
+  if (ilp == 4 && uc == 1)
+    warp_dice_sums_kernel<4, 1><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk);
+  else if (ilp == 4)
+    warp_dice_sums_kernel<4, 2><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk);
+  else if (uc == 1)
+    warp_dice_sums_kernel<2, 1><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk);
   else
-    warp_dice_sums_kernel<2><<<dim3((unsigned)nb, N), TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk);
+    warp_dice_sums_kernel<2, 2><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk);
   const int total = N * C * 3;
   warp_dice_final_kernel<<<ceil_div(total, TPB / kWave), TPB, 0, s>>>((const double*)ws, (int)nb, C, total, sums);
   return KMH_LAUNCH_CHECK();
@@ -1035,18 +1114,23 @@ KMH_API int kmh_warp_dice_sums(const float* x, const float* grid, const float* f
  * Autograd of keymorph/loss_ops.py:16-63 through keymorph/utils.py:14-21 in one pass. */
 KMH_API int kmh_warp_dice_bwd_grid(const float* x, const float* grid, const float* fixed, const float* ca, const float* cb,
                                    float* dgrid, int N, int C, int D, int H, int W, int Do, int Ho, int Wo, void* stream) {
-  if (N <= 0 || C <= 0 || !lane_contiguous_ok(D, H, W)) return -22;
+  if (N <= 0 || C <= 0 || !lane_contiguous_ok(D, H, W) || (long long)D * H * W >= (1ll << 30)) return -22;
   const long long ovox = (long long)Do * Ho * Wo;
   const int nchunk = ceil_div(ovox, (long long)TPB * PASSES);
-  static const int cap = getenv("KMH_WD_BLOCKS") ? atoi(getenv("KMH_WD_BLOCKS")) : 4096;
+  static const int cap = getenv("KMH_WD_BLOCKS") ? atoi(getenv("KMH_WD_BLOCKS")) : 768;
   static const int ilp = getenv("KMH_WD_ILP_B") ? atoi(getenv("KMH_WD_ILP_B")) : 2;
-  int nb = nchunk < cap ? nchunk : cap;
+  int per_n = (cap / N) & ~7;
+  if (per_n < 8) per_n = 8;
+  int nb = nchunk < per_n ? nchunk : per_n;
+  static const int uc = getenv("KMH_WD_UC") ? atoi(getenv("KMH_WD_UC")) : 1;
+  const dim3 g(nb, N);
+  hipStream_t s = (hipStream_t)stream;
   if (ilp == 4)
-    warp_dice_grad_kernel<4><<<dim3(nb, N), TPB, 0, (hipStream_t)stream>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox,
-                                                                           nchunk);
+    warp_dice_grad_kernel<4, 1><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk);
+  else if (uc == 1)
+    warp_dice_grad_kernel<2, 1><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk);
   else
-    warp_dice_grad_kernel<2><<<dim3(nb, N), TPB, 0, (hipStream_t)stream>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox,
-                                                                           nchunk);
+    warp_dice_grad_kernel<2, 2><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk);
   return KMH_LAUNCH_CHECK();
 }
 
