@@ -296,6 +296,21 @@ int kmh_gn_bwd_coeffs(const double* ab, const float* gamma, const float* mean_rs
 int kmh_gn_bwd_coeffs_fold(const double* dstats, const double* bhat, const float* gamma, const float* beta,
                            const float* mean_rstd, int N, int C, int G, double count, float* c123, float* dgamma,
                            float* dbeta, int* fallback, void* stream);
+/* ---- a3: ConvNet blocks with InstanceNorm kept lazy (keymorph/layers.py:137-187, norm_type "instance"; keymorph/net.py:7-36):
+ *      the next convolution's loader applies IN + ReLU to the RAW (max-pooled raw) output z, so InstanceNorm3d -> ReLU ->
+ *      [MaxPool3d(2)] has no forward pass of its own; its autograd, for du at the pooled resolution, zhat = z*scale + shift,
+ *      g = scatter(du) [zhat > 0]:  dz = c1 g + c2 z + c3  (c123 from kmh_gn_bwd_coeffs with G = C).
+ *      kmh_in_bwd_stats: out (N,C,2) doubles = (sum g, sum g z) taken at du's resolution (z = the pooled raw tensor there). */
+int kmh_in_bwd_stats(const float* du, const float* z, const float* scale, const float* shift, int N, long long V, int C,
+                     double* out, void* ws, void* stream);
+/*      no pooling between z and u: dz (N,V,C) = c1 du [zhat > 0] + c2 z + c3; dz may alias du; dz_scale2 | NULL = {S, 1/S} */
+int kmh_in_bwd_apply(const float* du, const float* z, const float* scale, const float* shift, const float* c123, int N,
+                     long long V, int C, float* dz, float* dz_scale2, void* stream);
+/*      through MaxPool3d(2): du (N,D/2,H/2,W/2,C), winners of kmh_maxpool3d_fwd on the raw z (N,D,H,W,C) -> dz (N,D,H,W,C) */
+int kmh_in_bwd_apply_pool(const unsigned char* argmax, const float* du, const float* z, const float* scale,
+                          const float* shift, const float* c123, int N, int D, int H, int W, int C, float* dz,
+                          float* dz_scale2, void* stream);
+
 /* dx_scale2 (float[2], ZERO on entry)|NULL: also emits {S, 1/S}, the f16x3 range scale of dx (what
  * kmh_absmax_scale(dx) would return), so the consumer convolution's backward needs no extra pass over its incoming
  * gradient. */

@@ -95,6 +95,9 @@ PROTOS = {
     "kmh_gn_bwd_coeffs": (_i, [_f, _f, _f, _i, _i, _i, C.c_double, _f, _f, _f, _f, _f]),
     "kmh_gn_bwd_coeffs_fold": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, C.c_double, _f, _f, _f, _f, _f]),
     "kmh_gn_bwd_apply": (_i, [_f, _f, _f, _i, _ll, _i, _i, _i, _f, _f, _i, _f]),
+    "kmh_in_bwd_stats": (_i, [_f, _f, _f, _f, _i, _ll, _i, _f, _f, _f]),
+    "kmh_in_bwd_apply": (_i, [_f, _f, _f, _f, _f, _i, _ll, _i, _f, _f, _f]),
+    "kmh_in_bwd_apply_pool": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f]),
     "kmh_relu_mask": (_i, [_f, _f, _ll, _f, _f]),
     "kmh_norm_apply": (_i, [_f, _f, _f, _i, _ll, _i, _i, _f, _f]),
     "kmh_maxpool3d_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f]),

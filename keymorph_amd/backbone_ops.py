@@ -1117,6 +1117,153 @@ def conv_block_batchnorm(x, weight, bias, bn: "torch.nn.modules.batchnorm._Batch
     return y
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# ConvNet with InstanceNorm kept lazy (keymorph/net.py:7-36, keymorph/layers.py:137-187, norm_type "instance").
+# A block of the reference is Conv3d -> InstanceNorm3d -> ReLU [-> MaxPool3d(2)].  Here the chain is cut at the RAW
+# convolution outputs z_b instead: unit b = InstanceNorm(z_{b-1}) -> ReLU -> [pool] -> Conv3d_b, and the normalisation, the
+# ReLU and -- because InstanceNorm without affine is increasing, so pooling commutes with it -- the pooling of the raw
+# tensor are applied by the convolution's own loader (scale / shift / relu_in of kmh_conv3d_fwd_bf and _wgrad_bf).  The
+# statistics of z_{b-1} come with the epilogue of the convolution that produced it.  No normalised tensor, no ReLU output
+# and no full-resolution pooling gradient is ever stored; the backward of the cut chain is three launches
+# (kmh_in_bwd_stats at the pooled resolution, kmh_gn_bwd_coeffs, kmh_in_bwd_apply[_pool]) around the two convolutions.
+# bench.py's ConvNet leg: 299 ms -> see DESIGN.md section 6.
+# ---------------------------------------------------------------------------------------------------------------------
+LAZY_IN_STATS = {"units": 0}
+
+
+def convnet_lazy_ok(x: Tensor, norm_type: str) -> bool:
+    """(N, D, H, W, C) NDHWC input of the ConvNet: four poolings need D, H, W % 16 == 0 for the even-size kernels; the
+    split-operand convolutions emit the statistics; KEYMORPH_NO_LAZY_IN=1 takes the block-by-block route (A/B, tests)."""
+    return (norm_type == "instance" and conv_emits_stats() and not os.environ.get("KEYMORPH_NO_LAZY_IN")
+            and all(int(d) % 16 == 0 for d in x.shape[1:4]))
+
+
+class _ConvINUnit(torch.autograd.Function):
+    """z = Conv3d_b(u) + bias with u = [MaxPool3d(2)](ReLU(InstanceNorm(zprev))) applied on the fly (zprev: the previous
+    block's raw convolution output with its epilogue statistics `st` (N, Cin, 2)); first unit: u = the image, no norm.
+    Returns (z, statistics of z)."""
+
+    @staticmethod
+    def forward(ctx, zprev, st, weight, bias, pool, first):
+        lib = _lib.load()
+        zprev, weight, bias = _prep(zprev), _prep(weight), _prep(bias)
+        N, Dp, Hp, Wp, Cin = zprev.shape
+        Cout = weight.shape[0]
+        ctx.first, ctx.pool = bool(first), bool(pool)
+        scale = shift = mr = ascale = arg = None
+        u = zprev
+        if not first:
+            scale, shift, mr, ascale = norm_coeffs(st, None, None, N, Cin, Cin, Dp * Hp * Wp, want_ascale=True)
+            if pool:
+                u = _f32((N, Dp // 2, Hp // 2, Wp // 2, Cin), zprev.device)
+                arg = torch.empty(u.shape, dtype=torch.uint8, device=zprev.device)
+                check(lib.kmh_maxpool3d_fwd(_p(zprev), _p(u), _p(arg), N, Dp, Hp, Wp, Cin, _stream()), "kmh_maxpool3d_fwd")
+        D, H, W = u.shape[1:4]
+        pk = pack_weight(weight, False)
+        ctx.wscale = getattr(pk, "_kmh_wscale", None)
+        zst = torch.empty((N, Cout, 2), dtype=torch.float64, device=zprev.device)
+        z = conv3_raw(u, scale, shift, pk, bias, N, D, H, W, Cin, Cout, not first, False, ascale=ascale, stats_out=zst)
+        ctx.ascale = ascale
+        ctx.dims = (N, Dp, Hp, Wp, D, H, W, Cin, Cout)
+        saved = [zprev, weight] + ([] if first else [scale, shift, mr]) + ([u, arg] if (pool and not first) else [])
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(zst)
+        LAZY_IN_STATS["units"] += 1
+        return z, zst
+
+    @staticmethod
+    def backward(ctx, dz, _dst):
+        lib = _lib.load()
+        N, Dp, Hp, Wp, D, H, W, Cin, Cout = ctx.dims
+        saved = ctx.saved_tensors
+        zprev, weight = saved[0], saved[1]
+        dscale = _peek_grad_scale(dz)
+        dz = _prep(dz)
+        if _needs_range_scales() and dscale is None:
+            dscale = absmax_scale(dz)
+        # InstanceNorm follows every convolution of this network: a bias shifts the mean and nothing else
+        db = torch.zeros(Cout, dtype=torch.float32, device=dz.device)
+        if ctx.first:
+            xs = absmax_scale(zprev) if _needs_range_scales() else None
+            dw = conv3_wgrad(zprev, None, None, dz, N, D, H, W, Cin, Cout, False, xscale=xs, dscale=dscale)
+            return None, None, dw, db, None, None
+        scale, shift, mr = saved[2:5]
+        u, arg = (saved[5], saved[6]) if ctx.pool else (zprev, None)
+        dw = conv3_wgrad(u, scale, shift, dz, N, D, H, W, Cin, Cout, True, xscale=ctx.ascale, dscale=dscale)
+        du = conv3_raw(dz, None, None, pack_weight(weight, True, wscale=ctx.wscale), None, N, D, H, W, Cout, Cin, False, False,
+                       ascale=dscale)
+        # g = scatter(du) [zhat > 0] lives at u's resolution: both sums of InstanceNorm's backward are taken there
+        ab = torch.empty((N, Cin, 2), dtype=torch.float64, device=dz.device)
+        ws = workspace(int(lib.kmh_channel_stats_ws_bytes(N, Cin)), dz.device, "stats")
+        check(lib.kmh_in_bwd_stats(_p(du), _p(u), _p(scale), _p(shift), N, D * H * W, Cin, _p(ab), _p(ws), _stream()),
+              "kmh_in_bwd_stats")
+        c123 = _f32((N, Cin, 3), dz.device)
+        check(lib.kmh_gn_bwd_coeffs(_p(ab), None, _p(mr), N, Cin, Cin, float(Dp * Hp * Wp), _p(c123), None, None, None,
+                                    _stream()), "kmh_gn_bwd_coeffs")
+        sc2 = torch.zeros(2, dtype=torch.float32, device=dz.device) if _needs_range_scales() else None
+        if ctx.pool:
+            dzp = _f32((N, Dp, Hp, Wp, Cin), dz.device)
+            check(lib.kmh_in_bwd_apply_pool(_p(arg), _p(du), _p(zprev), _p(scale), _p(shift), _p(c123), N, Dp, Hp, Wp, Cin,
+                                            _p(dzp), _p(sc2), _stream()), "kmh_in_bwd_apply_pool")
+        else:
+            dzp = du
+            check(lib.kmh_in_bwd_apply(_p(du), _p(zprev), _p(scale), _p(shift), _p(c123), N, Dp * Hp * Wp, Cin, _p(dzp),
+                                       _p(sc2), _stream()), "kmh_in_bwd_apply")
+        _tag_grad_scale(dzp, sc2)
+        return dzp, None, dw, db, None, None
+
+
+class _INReluOut(torch.autograd.Function):
+    """y = ReLU(InstanceNorm(z)) materialised (the network's output in front of the center of mass: 16^3 voxels)."""
+
+    @staticmethod
+    def forward(ctx, z, st):
+        lib = _lib.load()
+        z = _prep(z)
+        N, D, H, W, C = z.shape
+        V = D * H * W
+        scale, shift, mr = norm_coeffs(st, None, None, N, C, C, V)
+        y = torch.empty_like(z)
+        check(lib.kmh_norm_apply(_p(z), _p(scale), _p(shift), N, V, C, 1, _p(y), _stream()), "kmh_norm_apply")
+        ctx.save_for_backward(z, scale, shift, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        z, scale, shift, mr = ctx.saved_tensors
+        N, D, H, W, C = z.shape
+        V = D * H * W
+        dy = _prep(dy)
+        ab = torch.empty((N, C, 2), dtype=torch.float64, device=z.device)
+        ws = workspace(int(lib.kmh_channel_stats_ws_bytes(N, C)), z.device, "stats")
+        check(lib.kmh_in_bwd_stats(_p(dy), _p(z), _p(scale), _p(shift), N, V, C, _p(ab), _p(ws), _stream()), "kmh_in_bwd_stats")
+        c123 = _f32((N, C, 3), z.device)
+        check(lib.kmh_gn_bwd_coeffs(_p(ab), None, _p(mr), N, C, C, float(V), _p(c123), None, None, None, _stream()),
+              "kmh_gn_bwd_coeffs")
+        dz = torch.empty_like(z)
+        sc2 = torch.zeros(2, dtype=torch.float32, device=z.device) if _needs_range_scales() else None
+        check(lib.kmh_in_bwd_apply(_p(dy), _p(z), _p(scale), _p(shift), _p(c123), N, V, C, _p(dz), _p(sc2), _stream()),
+              "kmh_in_bwd_apply")
+        _tag_grad_scale(dz, sc2)
+        return dz, None
+
+
+def convnet_instance_lazy(x: Tensor, blocks) -> Tensor:
+    """The whole ConvNet (instance norm) on an NDHWC image: blocks = [(weight, bias, down_sample), ...] in order.
+    Returns ReLU(IN(conv_9(...))) [pooled if the last block pools], NDHWC."""
+    z = st = None
+    pool_prev = False
+    for b, (w, bias, down) in enumerate(blocks):
+        if b == 0:
+            z, st = _ConvINUnit.apply(x, None, w, bias, False, True)
+        else:
+            z, st = _ConvINUnit.apply(z, st, w, bias, pool_prev, False)
+        pool_prev = bool(down)
+    y = _INReluOut.apply(z, st)
+    return maxpool2(y) if pool_prev else y
+
+
 # The forward of the fused head stores [h > 0] (1 bit per voxel and keypoint channel: 0.5 GB for 4 x 128^3 x 512) when a
 # backward can follow, and the backward then skips recomputing the logits.  KEYMORPH_HEAD_MASK=0: always recompute.
 HEAD_MASK = os.environ.get("KEYMORPH_HEAD_MASK", "1") != "0"

@@ -301,6 +301,170 @@ __global__ __launch_bounds__(TPB) void relu_mask_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// ConvNet blocks with the normalisation kept LAZY (keymorph/layers.py:137-187, norm_type "instance"): a block's output
+// u = MaxPool(ReLU(IN(z))) is never stored -- the next convolution's loader normalises, rectifies and reads the raw z
+// (max-pooled raw: IN without affine is increasing, so pooling commutes with it).  Backward of that chain for an
+// incoming du (at u's resolution), with zhat = z * scale + shift and g = scatter(du) * [zhat > 0]:
+//     dz = rstd (g - mean g - zhat mean(g zhat)) = c1 g + c2 z + c3          (c123 from kmh_gn_bwd_coeffs with G = C)
+// g is non-zero at the pooling winners only, so the two sums are taken at u's resolution (in_bwd_stats_kernel) and the
+// apply pass reads du, the winners and z once and writes dz once (in_bwd_apply_pool_kernel): the unfused route ran a
+// pooling backward, a ReLU mask, a statistics pass and an apply pass over full-resolution tensors.
+
+// per (n, c): (sum g, sum g * z), g = du * [fma(z, scale, shift) > 0]; du, z (N, V, C) at the same resolution
+template <int VEC>
+__global__ __launch_bounds__(TPB) void in_bwd_stats_kernel(const float* __restrict__ du, const float* __restrict__ z,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           long long V, int C, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double sred[];  // [rows][C*2]
+  const int n = blockIdx.y;
+  const int CQ = C / VEC;
+  const int rows = TPB / CQ;
+  const int q = threadIdx.x % CQ, vl = threadIdx.x / CQ;
+  const bool active = vl < rows;
+  const long long per = (V + gridDim.x - 1) / gridDim.x;
+  const long long vbeg = per * blockIdx.x;
+  long long vend = vbeg + per;
+  if (vend > V) vend = V;
+  double d0[VEC], d1[VEC];
+  float f0[VEC], f1[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    d0[j] = d1[j] = 0.0; f0[j] = f1[j] = 0.f;
+    sc[j] = active ? scale[(long long)n * C + q * VEC + j] : 0.f;
+    sh[j] = active ? shift[(long long)n * C + q * VEC + j] : 0.f;
+  }
+  if (active) {
+    const float* ap = du + (long long)n * V * C + (long long)q * VEC;
+    const float* bp = z + (long long)n * V * C + (long long)q * VEC;
+    int cnt = 0;
+    for (long long v = vbeg + vl; v < vend; v += rows) {
+      float av[VEC], bv[VEC];
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(ap + v * C);
+        const float4 u = *reinterpret_cast<const float4*>(bp + v * C);
+        av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+        bv[0] = u.x; bv[1] = u.y; bv[2] = u.z; bv[3] = u.w;
+      } else {
+        av[0] = ap[v * C];
+        bv[0] = bp[v * C];
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float g = fmaf(bv[j], sc[j], sh[j]) > 0.f ? av[j] : 0.f;
+        f0[j] += g;
+        f1[j] += g * bv[j];
+      }
+      if (++cnt == 64) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { d0[j] += f0[j]; d1[j] += f1[j]; f0[j] = f1[j] = 0.f; }
+        cnt = 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { d0[j] += f0[j]; d1[j] += f1[j]; }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      sred[((long long)vl * C + q * VEC + j) * 2] = d0[j];
+      sred[((long long)vl * C + q * VEC + j) * 2 + 1] = d1[j];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < C * 2; e += TPB) {
+    double s = 0;
+    for (int r = 0; r < rows; ++r) s += sred[(long long)r * C * 2 + e];
+    partial[((long long)n * gridDim.x + blockIdx.x) * C * 2 + e] = s;
+  }
+}
+
+// dz = c1 * du * [fma(z, scale, shift) > 0] + c2 * z + c3   (no pooling between z and u); dz may alias du
+__global__ __launch_bounds__(TPB) void in_bwd_apply_kernel(const float* du, const float* __restrict__ z,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ c123, long long V, int C, float* dz,
+                                                           unsigned* __restrict__ amax) {
+  const int n = blockIdx.y;
+  const long long total = V * C, base = (long long)n * total;
+  const float* cc = c123 + (long long)n * C * 3;
+  const float* sc = scale + (long long)n * C;
+  const float* sh = shift + (long long)n * C;
+  float mx = 0.f;
+  if ((C & 3) == 0) {
+    const long long t4 = total >> 2;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < t4; e += (long long)gridDim.x * TPB) {
+      const int c = (int)((e * 4) % C);
+      const float4 g4 = *reinterpret_cast<const float4*>(du + base + e * 4);
+      const float4 z4 = *reinterpret_cast<const float4*>(z + base + e * 4);
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
+      float r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = fmaf(zz[j], sc[c + j], sh[c + j]) > 0.f ? gg[j] : 0.f;
+        r[j] = cc[(c + j) * 3] * g + cc[(c + j) * 3 + 1] * zz[j] + cc[(c + j) * 3 + 2];
+      }
+      *reinterpret_cast<float4*>(dz + base + e * 4) = make_float4(r[0], r[1], r[2], r[3]);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r[0]), fabsf(r[1]))), fmaxf(fabsf(r[2]), fabsf(r[3])));
+    }
+  } else {
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+      const int c = (int)(e % C);
+      const float zv = z[base + e];
+      const float g = fmaf(zv, sc[c], sh[c]) > 0.f ? du[base + e] : 0.f;
+      const float v = cc[c * 3] * g + cc[c * 3 + 1] * zv + cc[c * 3 + 2];
+      dz[base + e] = v;
+      mx = fmaxf(mx, fabsf(v));
+    }
+  }
+  if (amax) kmh_absmax::publish(mx, amax);
+}
+
+// dz (full resolution) = c1 * scatter(du * [zhat(winner) > 0]) + c2 * z + c3: MaxPool3d(2)'s backward (winners from
+// kmh_maxpool3d_fwd on the RAW z), the ReLU mask and InstanceNorm's backward in ONE pass; even D, H, W, C % 4 == 0
+__global__ __launch_bounds__(TPB) void in_bwd_apply_pool_kernel(const unsigned* __restrict__ argm, const float4* __restrict__ du,
+                                                                const float4* __restrict__ z, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ c123,
+                                                                float4* __restrict__ dz, int D, int H, int W, int C4, int Do,
+                                                                int Ho, int Wo, unsigned* __restrict__ amax) {
+  const int n = blockIdx.y;
+  const int total = Do * Ho * Wo * C4;
+  const long long V = (long long)D * H * W;
+  const float4* zn = z + (long long)n * V * C4;
+  float4* dzo = dz + (long long)n * V * C4;
+  const float* cc = c123 + (long long)n * C4 * 12;
+  const float* sc = scale + (long long)n * C4 * 4;
+  const float* sh = shift + (long long)n * C4 * 4;
+  float mx = 0.f;
+  for (int e = blockIdx.x * TPB + threadIdx.x; e < total; e += gridDim.x * TPB) {
+    const int c = e % C4, v = e / C4;
+    const int xo = v % Wo, r = v / Wo, yo = r % Ho, zo = r / Ho;
+    const unsigned a = argm[(long long)n * total + e];
+    const float4 g = du[(long long)n * total + e];
+    const int aw[4] = {(int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255), (int)(a >> 24)};
+    const float gg[4] = {g.x, g.y, g.z, g.w};
+    float k1[4], k2[4], k3[4], s1[4], s0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      k1[j] = cc[(4 * c + j) * 3]; k2[j] = cc[(4 * c + j) * 3 + 1]; k3[j] = cc[(4 * c + j) * 3 + 2];
+      s1[j] = sc[4 * c + j]; s0[j] = sh[4 * c + j];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int zz = 2 * zo + (k >> 2), yy = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+      const long long o = ((long long)(zz * H + yy) * W + xx) * C4 + c;
+      const float4 z4 = zn[o];
+      const float zv[4] = {z4.x, z4.y, z4.z, z4.w};
+      float t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gj = (k == aw[j] && fmaf(zv[j], s1[j], s0[j]) > 0.f) ? gg[j] : 0.f;
+        t[j] = k1[j] * gj + k2[j] * zv[j] + k3[j];
+      }
+      dzo[o] = make_float4(t[0], t[1], t[2], t[3]);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
+    }
+  }
+  if (amax) kmh_absmax::publish(mx, amax);
+}
+
+// ---------------------------------------------------------------------------------------------
 // MaxPool3d(2), floor mode, NDHWC
 __global__ __launch_bounds__(TPB) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           unsigned char* __restrict__ arg /* window index | NULL */, int D,
@@ -884,6 +1048,65 @@ KMH_API int kmh_norm_apply(const float* x, const float* scale, const float* shif
                            int relu, float* y, void* stream) {
   norm_apply_kernel<<<dim3(stream_blocks(V * C / 4), N), TPB, 0, (hipStream_t)stream>>>(x, scale, shift, V, C, relu,
                                                                                        y);
+  return KMH_LAUNCH_CHECK();
+}
+
+/* Lazy InstanceNorm blocks (keymorph/layers.py:137-187 with norm_type "instance"; autograd of InstanceNorm3d -> ReLU ->
+ * [MaxPool3d(2)] in one piece).  out (N,C,2) doubles = (sum g, sum g*z), g = du * [fma(z, scale, shift) > 0]; du, z (N,V,C). */
+KMH_API int kmh_in_bwd_stats(const float* du, const float* z, const float* scale, const float* shift, int N, long long V,
+                             int C, double* out, void* ws, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (C > TPB * 4) return -22;
+  int nblk = ceil_div(V, 2048);
+  if (nblk > STAT_BLOCKS) nblk = STAT_BLOCKS;
+  if (nblk < 1) nblk = 1;
+  const bool v4 = (C % 4 == 0) && (C / 4 <= TPB);
+  const int CQ = v4 ? C / 4 : C;
+  if (CQ > TPB) return -22;
+  const int rows = TPB / CQ;
+  const size_t lds = (size_t)rows * C * 2 * sizeof(double);
+  if (lds > 64 * 1024) return -22;
+  dim3 g(nblk, N);
+  if (v4) in_bwd_stats_kernel<4><<<g, TPB, lds, s>>>(du, z, scale, shift, V, C, (double*)ws);
+  else in_bwd_stats_kernel<1><<<g, TPB, lds, s>>>(du, z, scale, shift, V, C, (double*)ws);
+  kmh_stats::final_kernel<<<dim3(ceil_div(C * 2, 256 / kWave), N), 256, 0, s>>>((const double*)ws, nblk, C, out, nullptr);
+  return KMH_LAUNCH_CHECK();
+}
+
+/* dz = c1 g + c2 z + c3 with g as above (c123 (N,C,3) from kmh_gn_bwd_coeffs with G = C); dz may alias du; dz_scale2
+ * (2 floats) | NULL receives the f16x3 range scale {S, 1/S} of max |dz|. */
+KMH_API int kmh_in_bwd_apply(const float* du, const float* z, const float* scale, const float* shift, const float* c123,
+                             int N, long long V, int C, float* dz, float* dz_scale2, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (dz_scale2) {
+    hipError_t e = hipMemsetAsync(dz_scale2, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  in_bwd_apply_kernel<<<dim3(stream_blocks(V * C / 4), N), TPB, 0, s>>>(du, z, scale, shift, c123, V, C, dz,
+                                                                       reinterpret_cast<unsigned*>(dz_scale2));
+  if (dz_scale2) kmh_absmax::final_kernel<<<1, 1, 0, s>>>(dz_scale2, 0.f);
+  return KMH_LAUNCH_CHECK();
+}
+
+/* the same through MaxPool3d(2): du (N,D/2,H/2,W/2,C) and the winners of kmh_maxpool3d_fwd on the raw z (N,D,H,W,C);
+ * dz (N,D,H,W,C) = c1 scatter(du [zhat(winner) > 0]) + c2 z + c3.  Even D, H, W; C % 4 == 0; 16-byte aligned tensors. */
+KMH_API int kmh_in_bwd_apply_pool(const unsigned char* argmax, const float* du, const float* z, const float* scale,
+                                  const float* shift, const float* c123, int N, int D, int H, int W, int C, float* dz,
+                                  float* dz_scale2, void* stream) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const long long pooled = (long long)Do * Ho * Wo * C;
+  if (!argmax || !du || !z || !c123 || !dz || (C & 3) || (D & 1) || (H & 1) || (W & 1)) return -22;
+  if (pooled / 4 >= (1ll << 31) || (long long)D * H * W >= (1ll << 31)) return -22;
+  if ((((uintptr_t)du | (uintptr_t)z | (uintptr_t)dz) & 15) || ((uintptr_t)argmax & 3)) return -22;
+  hipStream_t s = (hipStream_t)stream;
+  if (dz_scale2) {
+    hipError_t e = hipMemsetAsync(dz_scale2, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  in_bwd_apply_pool_kernel<<<dim3(stream_blocks(pooled), N), TPB, 0, s>>>(
+      (const unsigned*)argmax, (const float4*)du, (const float4*)z, scale, shift, c123, (float4*)dz, D, H, W, C / 4, Do, Ho, Wo,
+      reinterpret_cast<unsigned*>(dz_scale2));
+  if (dz_scale2) kmh_absmax::final_kernel<<<1, 1, 0, s>>>(dz_scale2, 0.f);
   return KMH_LAUNCH_CHECK();
 }
 

@@ -54,6 +54,12 @@ class ConvNet(nn.Module):
 
     def forward(self, x):
         out = B.to_ndhwc(x)
-        for b in range(1, 10):
-            out = getattr(self, f"block{b}")(out)
+        blocks = [getattr(self, f"block{b}") for b in range(1, 10)]
+        if B.convnet_lazy_ok(out, blocks[0].norm_type):
+            # InstanceNorm + ReLU + MaxPool applied inside the NEXT convolution's loader: nothing but the raw convolution
+            # outputs is stored (backbone_ops.convnet_instance_lazy)
+            out = B.convnet_instance_lazy(out, [(m.conv.weight, m.conv.bias, m.down_sample) for m in blocks])
+        else:
+            for m in blocks:
+                out = m(out)
         return B.to_ncdhw(out)

@@ -273,6 +273,49 @@ def test_convnet_golden(norm):
         assert e < 3e-2, (k, e)
 
 
+@pytest.mark.parametrize("shape,N", [((32, 32, 32), 1), ((16, 48, 32), 2)])
+def test_convnet_lazy_instance_norm_equals_block_by_block(shape, N, monkeypatch):
+    """ConvNet(instance): the lazy route (IN + ReLU + MaxPool inside the next convolution's loader, three-launch backward:
+    backbone_ops.convnet_instance_lazy) against the block-by-block route (KEYMORPH_NO_LAZY_IN=1: conv, statistics pass,
+    norm apply, pooling, and their separate backward passes) and against the oracle's autograd (keymorph/net.py:7-36,
+    layers.py:137-187): same keypoint logits, every weight gradient at the fp32 rounding level of the two HIP routes."""
+    from keymorph_amd import backbone_ops as B
+    from keymorph_amd.net import ConvNet
+    from oracle import keymorph_oracle as O
+    from tests.util import convnet_shapes
+    shapes = convnet_shapes(8)
+    sd = seeded_state_dict(shapes, 101)
+    x = torch.rand((N, 1) + shape, generator=gen(11))
+    outs = {}
+    for lazy in (True, False):
+        if lazy:
+            monkeypatch.delenv("KEYMORPH_NO_LAZY_IN", raising=False)
+        else:
+            monkeypatch.setenv("KEYMORPH_NO_LAZY_IN", "1")
+        net = ConvNet(3, 1, 8, "instance")
+        net.load_state_dict(sd, strict=True)
+        net = net.to(DEV).train()
+        before = B.LAZY_IN_STATS["units"]
+        y = net(x.to(DEV))
+        assert (B.LAZY_IN_STATS["units"] - before) == (9 if lazy else 0)
+        cot = torch.linspace(-1, 1, y.numel(), device=DEV).reshape(y.shape)
+        (y * cot).sum().backward()
+        outs[lazy] = (y.detach().cpu(), {k: p.grad.detach().cpu().double() for k, p in net.named_parameters()})
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yr = O.convnet_forward(sdr, x, "instance")
+    (yr * torch.linspace(-1, 1, yr.numel()).reshape(yr.shape)).sum().backward()
+    scale = max(1.0, float(yr.abs().max()))
+    close(outs[True][0], yr.detach(), 2e-4 * scale, 1e-3)
+    close(outs[True][0], outs[False][0], 2e-5 * scale, 1e-4)
+    for k in outs[True][1]:
+        a, b, r = outs[True][1][k], outs[False][1][k], sdr[k].grad.double()
+        if k.endswith("conv.bias"):          # d/d(bias) == 0 under InstanceNorm: exactly 0 here, round-off in the others
+            assert float(a.abs().max()) == 0.0 and float(r.norm()) < 1e-3 * float(sdr[k.replace("bias", "weight")].grad.norm())
+            continue
+        assert float((a - b).norm() / (b.norm() + 1e-30)) < 2e-3, (k, "lazy vs block-by-block")
+        assert float((a - r).norm() / (r.norm() + 1e-30)) < 3e-2, (k, "lazy vs oracle")
+
+
 def test_convblock_group_norm():
     from keymorph_amd import backbone_ops as B
     g = gen(5)

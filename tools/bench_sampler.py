@@ -34,3 +34,9 @@ t = timeit(lambda: lib.kmh_grid_sample3d_fwd(p(x), p(grid), p(out), 1, 1, S, S, 
 print(f"sample_fwd     {t*1e3:8.1f} us  {V*20/t/1e6:8.1f} GB/s (20 B/voxel)   sum {float(out.double().sum()):.4f}")
 t = timeit(lambda: lib.kmh_grid_sample3d_bwd_grid(p(x), p(grid), p(f), p(dg), 1, 1, S, S, S, S, S, S, st))
 print(f"sample_bwd_grid{t*1e3:8.1f} us  {V*32/t/1e6:8.1f} GB/s (32 B/voxel)   sum {float(dg.double().abs().sum()):.4f}")
+for C in (1, 14):
+    xs = torch.rand(1, C, S, S, S, device=dev, generator=g); outs = torch.empty_like(xs)
+    t = timeit(lambda: lib.kmh_grid_sample3d_fwd(p(xs), p(grid), p(outs), 1, C, S, S, S, S, S, S, 0, st), n=10)
+    print(f"sample_fwd C={C:2d} {t*1e3:8.1f} us  {V*(12+8*C)/t/1e6:8.1f} GB/s ({12+8*C} B/voxel)  [KMH_SAMPLER_XCD={os.environ.get('KMH_SAMPLER_XCD','1')}]")
+t = timeit(lambda: lib.kmh_warp_mse_fwd_grad(p(x), p(grid), p(f), p(out), p(loss), p(dg), 1, 1, S, S, S, S, S, S, p(ws), st))
+print(f"warp_mse_fwd_grad {t*1e3:8.1f} us  {V*36/t/1e6:8.1f} GB/s (36 B/voxel)")

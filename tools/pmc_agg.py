@@ -11,7 +11,7 @@ for d in sys.argv[1:]:
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k].add(r["Dispatch_Id"])
 for k, v in agg.items():
-    if not any(t in k for t in ("conv3", "headcom", "tps", "sample", "warp_dice")):
+    if not any(t in k for t in ("conv3", "headcom", "tps", "sample", "warp_dice", "dice_partial", "elementwise", "copy")):
         continue
     print(k)
     for c, x in sorted(v.items()):
