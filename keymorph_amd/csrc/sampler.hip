@@ -602,7 +602,10 @@ __global__ __launch_bounds__(TPB) void warp_dice_sums_kernel(
       for (int u = 0; u < WD_ILP; ++u) {
         const int l = tid + (j0 + u) * TPB;
         q[u] = make_tapb(make_tap(sg[l * 3], sg[l * 3 + 1], sg[l * 3 + 2], D, H, W), D, H, W);
-        if (l >= cnt) q[u].o00 = q[u].o01 = q[u].o10 = q[u].o11 = plane_bytes;      // past the range check: reads 0
+        if (l >= cnt) {     // past the chunk: every corner reads 0 through the range check, and the weights must be finite
+          q[u].o00 = q[u].o01 = q[u].o10 = q[u].o11 = plane_bytes;      // (sg holds stale LDS there: 0 * NaN would poison
+          q[u].fx = q[u].fy = q[u].fz = 0.f;                             //  the wave's sums)
+        }
       }
       const int left = cnt - j0 * TPB;                 // voxels of the chunk from this sub-pass on (may be <= 0)
       const unsigned fbytes = left > 0 ? 4u * (unsigned)left : 0u;
@@ -695,7 +698,10 @@ __global__ __launch_bounds__(TPB) void warp_dice_grad_kernel(
       for (int u = 0; u < WD_ILP; ++u) {
         const int l = tid + (j0 + u) * TPB;
         q[u] = make_tapb(make_tap(sg[l * 3], sg[l * 3 + 1], sg[l * 3 + 2], D, H, W), D, H, W);
-        if (l >= cnt) q[u].o00 = q[u].o01 = q[u].o10 = q[u].o11 = plane_bytes;      // reads 0: no contribution
+        if (l >= cnt) {     // reads 0 with finite weights: no contribution (and nothing of this row is stored)
+          q[u].o00 = q[u].o01 = q[u].o10 = q[u].o11 = plane_bytes;
+          q[u].fx = q[u].fy = q[u].fz = 0.f;
+        }
         gx[u] = gy[u] = gz[u] = 0.f;
       }
       const int left = cnt - j0 * TPB;
@@ -934,8 +940,10 @@ __global__ __launch_bounds__(TPB) void jacdet_final_kernel(const double* __restr
   }
 }
 
-static int sampler_xcd() {      // A/B switch: KMH_SAMPLER_XCD=0 deals the chunks round-robin over the XCDs again
-  static const int v = getenv("KMH_SAMPLER_XCD") ? atoi(getenv("KMH_SAMPLER_XCD")) : 1;
+static int sampler_xcd() {      // A/B switch, OFF by default: one contiguous chunk range per XCD measured 102.6 us vs 88.7 us
+                                // (C = 1, 256^3) and flat for C = 14 -- the L2s' duplicate fetches are served by the
+                                // Infinity Cache, and contiguous ranges concentrate each XCD on fewer HBM channels
+  static const int v = getenv("KMH_SAMPLER_XCD") ? atoi(getenv("KMH_SAMPLER_XCD")) : 0;
   return v;
 }
 static bool lane_contiguous_ok(int D, int H, int W) {
@@ -1118,7 +1126,7 @@ KMH_API int kmh_warp_dice_bwd_grid(const float* x, const float* grid, const floa
   const long long ovox = (long long)Do * Ho * Wo;
   const int nchunk = ceil_div(ovox, (long long)TPB * PASSES);
   static const int cap = getenv("KMH_WD_BLOCKS") ? atoi(getenv("KMH_WD_BLOCKS")) : 768;
-  static const int ilp = getenv("KMH_WD_ILP_B") ? atoi(getenv("KMH_WD_ILP_B")) : 2;
+  static const int ilp = getenv("KMH_WD_ILP_B") ? atoi(getenv("KMH_WD_ILP_B")) : 4;      // 1.97 ms vs 2.58 (ILP 2) at 2 x 14 x 256^3
   int per_n = (cap / N) & ~7;
   if (per_n < 8) per_n = 8;
   int nb = nchunk < per_n ? nchunk : per_n;
