@@ -450,17 +450,10 @@ def test_fullsize_vs_oracle_256_affine():
     assert par["tail_rel_l2_hip"] <= max(1e-4, 1.25 * par["tail_rel_l2_oracle"]), par
     assert par["gradient_rel_l2"] <= 2e-3 + 2 * (par["tail_rel_l2_hip"] + par["tail_rel_l2_oracle"]), par
 
-    # tps_1, forward only, same pair and weights: the oracle's fit on ITS keypoints at sampled voxels (4 sub-grids in the
-    # reference's eval mode change nothing per voxel: keypoint_aligners.py:365-433)
-    km = hip_model(ref["sd"], K, DEV).eval()
-    with torch.no_grad():
-        grid = km(ref["img_f"].to(DEV), ref["img_m"].to(DEV), transform_type="tps_1", return_aligned_points=False)["tps_1"]["grid"]
-    gen = torch.Generator().manual_seed(5)
-    idx = [torch.randint(0, SIZE, (4096,), generator=gen) for _ in range(3)]
-    g = O.base_grid((SIZE, SIZE, SIZE))[idx[0], idx[1], idx[2]].reshape(1, -1, 3)
-    lm = torch.full((1,), 1.0)
-    want = O.tps_transform_points(O.tps_fit(ref["points_f"], ref["points_m"], lm), ref["points_f"], g).flip(-1)[0]
-    got = grid[0][idx[0].to(DEV), idx[1].to(DEV), idx[2].to(DEV)].cpu()
-    err = float((got - want).abs().max())
-    print(f"256^3 tps_1 grid at 4096 sampled voxels vs oracle: {err:.2e}")
-    assert err <= 1e-4, err
+    # forward-only legs from the same oracle run (tests/oracle_at_size.py::extra_legs): TPS grids at 4096 sampled voxels on
+    # the ORACLE's keypoints, and the 14-class Dice (north_star: "matching reference Dice within 1e-4")
+    assert par["tps_1_grid_vs_oracle_fp32"] <= 1e-4 and par["tps_1_e2e_grid_vs_oracle_fp32"] <= 1e-4, par
+    # lambda = 0, 512 clumped keypoints = the metric's own configuration, ill-conditioned: no further from the
+    # fp64 truth than 1.25 x the reference arithmetic's own fp32 error (or 1e-4)
+    assert par["tps_0_grid_vs_fp64"] <= max(1e-4, 1.25 * par["tps_0_oracle_fp32_vs_fp64"]), par
+    assert par["dice_fused"] <= 1e-4 and par["dice_unfused"] <= 1e-4, par

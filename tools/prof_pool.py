@@ -1,6 +1,9 @@
 """time / trace the pooling-epilogue convolution (16 -> 32 at 256^3, N = 2) next to the plain one + separate pooling"""
 import os, sys, torch
 sys.path.insert(0, '.')
+if os.environ.get('KMH_LIB'):
+    from keymorph_amd import _lib as _l
+    _l.LIBPATH = os.environ['KMH_LIB']
 from keymorph_amd import backbone_ops as B
 B.set_conv_mode("f16x3")
 dev = "cuda"
