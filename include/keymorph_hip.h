@@ -69,11 +69,18 @@ int kmh_rows_axpby(const float* t, const float* p, const float* ca, const float*
  *      sums[(n*C + c)*3 + {0,1,2}] = {sum t p, sum p^2, sum t^2}, p = grid_sample(x, grid)[n,c], t = fixed[n,c].
  *      -22 when the lane-contiguous sampler does not apply (W < 2, plane >= 2^31 voxels, C > 128). */
 int kmh_warp_dice_sums(const float* x, const float* grid, const float* fixed, float* sums, int N, int C, int D, int H,
-                       int W, int Do, int Ho, int Wo, void* ws, void* stream);
+                       int W, int Do, int Ho, int Wo, const unsigned char* lab_x, const unsigned char* lab_fixed,
+                       const int* gate, void* ws, void* stream);
 /* its backward (autograd of keymorph/loss_ops.py:16-63 through keymorph/utils.py:14-21, one pass):
  *      dgrid[n,v,:] = sum_c (ca[n*C+c] t + cb[n*C+c] p) * d p / d grid, with ca = -2 g / den, cb = 2 g num / den^2. */
 int kmh_warp_dice_bwd_grid(const float* x, const float* grid, const float* fixed, const float* ca, const float* cb,
-                           float* dgrid, int N, int C, int D, int H, int W, int Do, int Ho, int Wo, void* stream);
+                           float* dgrid, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
+                           const unsigned char* lab_x, const unsigned char* lab_fixed, const int* gate, void* stream);
+/*      lab_x (N, D*H*W) / lab_fixed (N, Do*Ho*Wo) / gate: all NULL, or the label maps and the device flag written by
+ *      kmh_onehot_to_labels: one-hot segmentations (what keymorph/utils.py:200-240 + nearest-sampled augmentation produce,
+ *      scripts/train.py:54-98) are then read as ONE byte per voxel (8 corner labels gathered once instead of 8 corner
+ *      values per channel), bit-identical results; gate[0] == 0 (a soft segmentation) -> the float tensors are read. */
+int kmh_onehot_to_labels(const float* x, int N, int C, long long V, unsigned char* lab, int* ok, void* stream);
 /* hard Dice: onehot(argmax_c pred) over (N,C,V) -> out (N,C,V); first max wins like torch.argmax */
 int kmh_argmax_onehot(const float* pred, int N, int C, long long V, float* out, void* stream);
 /* keymorph/loss_ops.py:161-247 (_jacobian_determinant, jdstd, jdlessthan0): central differences with zero padding

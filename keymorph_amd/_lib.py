@@ -30,8 +30,9 @@ PROTOS = {
     "kmh_scale_unless_one": (_i, [_f, _ll, _f, _f]),
     "kmh_dice_sums": (_i, [_f, _f, _i, _ll, _f, _f, _f]),
     "kmh_rows_axpby": (_i, [_f, _f, _f, _f, _i, _ll, _f, _f]),
-    "kmh_warp_dice_sums": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f]),
-    "kmh_warp_dice_bwd_grid": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f]),
+    "kmh_warp_dice_sums": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "kmh_warp_dice_bwd_grid": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "kmh_onehot_to_labels": (_i, [_f, _i, _i, _ll, _f, _f, _f]),
     "kmh_argmax_onehot": (_i, [_f, _i, _i, _ll, _f, _f]),
     "kmh_affine_grid_fwd": (_i, [_f, _f, _i, _i, _i, _i, _f]),
     "kmh_affine_grid_bwd": (_i, [_f, _f, _i, _i, _i, _i, _f, _f]),

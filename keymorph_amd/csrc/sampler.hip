@@ -557,11 +557,35 @@ __device__ __forceinline__ ChunkWalk chunk_walk(int b, int nb, int nchunk) {
   return w;
 }
 
+// LAB variants: both segmentations are exactly one-hot (what scripts/train.py:54-79 builds: one_hot of a label map,
+// augmented with NEAREST sampling), so a voxel's C channel values are determined by ONE byte.  kmh_onehot_to_labels checks
+// that on the device and writes the label maps; the kernels then gather 8 corner LABELS per voxel once instead of 8 corner
+// values per channel (56 B of gathers and 56 B of fixed-segmentation reads per voxel become 8 + 1), and feed
+// v_k = [label_k == c] into the SAME blend / derivative arithmetic: bit-identical results.  `gate` (device int): the LAB
+// kernels return at once when it reads 0, the dense ones when it reads non-zero -- no host synchronisation decides.
+struct LabTaps { unsigned c[8]; unsigned t; };      // 8 corner labels (255 = none) and the fixed label
+__device__ __forceinline__ unsigned ld_lab(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off, 0, 0) & 255u;
+}
+// q's byte offsets are 4 * voxel index: the label map has one byte per voxel
+__device__ __forceinline__ void gather_labels(__amdgpu_buffer_rsrc_t r, const TapB& q, bool live, LabTaps& L) {
+  const unsigned o[4] = {q.o00 >> 2, q.o01 >> 2, q.o10 >> 2, q.o11 >> 2};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned a = ld_lab(r, o[k]), b = ld_lab(r, o[k] + 1u);
+    L.c[2 * k] = live ? (q.sel ? b : a) : 255u;             // as pair_b: the last column's pair sits one to the left
+    L.c[2 * k + 1] = (live && !q.sel) ? b : 255u;
+  }
+}
+
 // partial: (N, gridDim.x, C, 3) doubles
-template <int WD_ILP, int UC = 1>
+template <int WD_ILP, int UC = 1, bool LAB = false>
 __global__ __launch_bounds__(TPB) void warp_dice_sums_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ fixed,
-    double* __restrict__ partial, int C, int D, int H, int W, long long ovox, int nchunk) {
+    double* __restrict__ partial, int C, int D, int H, int W, long long ovox, int nchunk,
+    const unsigned char* __restrict__ labx = nullptr, const unsigned char* __restrict__ labf = nullptr,
+    const int* __restrict__ gate = nullptr) {
+  if (gate && ((*gate != 0) != LAB)) return;           // uniform: the other variant of this launch pair does the work
   __shared__ __attribute__((aligned(16))) float sg[TPB * PASSES * 3];
   __shared__ double racc[TPB / kWave][WD_MAXC][3];
   const int n = blockIdx.y, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
@@ -609,15 +633,38 @@ __global__ __launch_bounds__(TPB) void warp_dice_sums_kernel(
       }
       const int left = cnt - j0 * TPB;                 // voxels of the chunk from this sub-pass on (may be <= 0)
       const unsigned fbytes = left > 0 ? 4u * (unsigned)left : 0u;
-#pragma unroll UC
-      for (int c = 0; c < C; ++c) {
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + ((long long)n * C + c) * plane, plane_bytes);
-        const __amdgpu_buffer_rsrc_t rf = make_rsrc(fixed + ((long long)n * C + c) * ovox + vb + j0 * TPB, fbytes);
-        float v[WD_ILP][8], tv[WD_ILP];
+      LabTaps lab[WD_ILP];
+      if constexpr (LAB) {
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char*>(labx + (long long)n * plane), 0, (int)plane, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char*>(labf + (long long)n * ovox + vb + j0 * TPB), 0, left > 0 ? left : 0, 0x00020000);
 #pragma unroll
         for (int u = 0; u < WD_ILP; ++u) {
-          gather8_b(rx, q[u], v[u]);
-          tv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, 4 * (tid + u * TPB), 0, 0));
+          const bool live = tid + (j0 + u) * TPB < cnt;
+          gather_labels(rl, q[u], live, lab[u]);
+          const unsigned t = ld_lab(rt, (unsigned)(tid + u * TPB));
+          lab[u].t = live ? t : 255u;
+        }
+      }
+#pragma unroll UC
+      for (int c = 0; c < C; ++c) {
+        float v[WD_ILP][8], tv[WD_ILP];
+        if constexpr (LAB) {
+#pragma unroll
+          for (int u = 0; u < WD_ILP; ++u) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[u][k] = lab[u].c[k] == (unsigned)c ? 1.f : 0.f;
+            tv[u] = lab[u].t == (unsigned)c ? 1.f : 0.f;
+          }
+        } else {
+          const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + ((long long)n * C + c) * plane, plane_bytes);
+          const __amdgpu_buffer_rsrc_t rf = make_rsrc(fixed + ((long long)n * C + c) * ovox + vb + j0 * TPB, fbytes);
+#pragma unroll
+          for (int u = 0; u < WD_ILP; ++u) {
+            gather8_b(rx, q[u], v[u]);
+            tv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, 4 * (tid + u * TPB), 0, 0));
+          }
         }
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -654,11 +701,13 @@ __global__ __launch_bounds__(TPB) void warp_dice_final_kernel(const double* __re
   if (lane == 0) sums[e] = (float)s;
 }
 
-template <int WD_ILP, int UC = 1>
+template <int WD_ILP, int UC = 1, bool LAB = false>
 __global__ __launch_bounds__(TPB) void warp_dice_grad_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ fixed,
     const float* __restrict__ ca, const float* __restrict__ cb, float* __restrict__ dgrid, int C, int D, int H, int W,
-    long long ovox, int nchunk) {
+    long long ovox, int nchunk, const unsigned char* __restrict__ labx = nullptr,
+    const unsigned char* __restrict__ labf = nullptr, const int* __restrict__ gate = nullptr) {
+  if (gate && ((*gate != 0) != LAB)) return;
   __shared__ __attribute__((aligned(16))) float sg[TPB * PASSES * 3];
   const int n = blockIdx.y, tid = threadIdx.x;
   const long long plane = (long long)D * H * W;
@@ -706,16 +755,39 @@ __global__ __launch_bounds__(TPB) void warp_dice_grad_kernel(
       }
       const int left = cnt - j0 * TPB;
       const unsigned fbytes = left > 0 ? 4u * (unsigned)left : 0u;
-#pragma unroll UC
-      for (int c = 0; c < C; ++c) {
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + ((long long)n * C + c) * plane, plane_bytes);
-        const __amdgpu_buffer_rsrc_t rf = make_rsrc(fixed + ((long long)n * C + c) * ovox + vb + j0 * TPB, fbytes);
-        const float a = ca[n * C + c], b = cb[n * C + c];
-        float v[WD_ILP][8], tv[WD_ILP];
+      LabTaps lab[WD_ILP];
+      if constexpr (LAB) {
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char*>(labx + (long long)n * plane), 0, (int)plane, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char*>(labf + (long long)n * ovox + vb + j0 * TPB), 0, left > 0 ? left : 0, 0x00020000);
 #pragma unroll
         for (int u = 0; u < WD_ILP; ++u) {
-          gather8_b(rx, q[u], v[u]);
-          tv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, 4 * (tid + u * TPB), 0, 0));
+          const bool live = tid + (j0 + u) * TPB < cnt;
+          gather_labels(rl, q[u], live, lab[u]);
+          const unsigned t = ld_lab(rt, (unsigned)(tid + u * TPB));
+          lab[u].t = live ? t : 255u;
+        }
+      }
+#pragma unroll UC
+      for (int c = 0; c < C; ++c) {
+        const float a = ca[n * C + c], b = cb[n * C + c];
+        float v[WD_ILP][8], tv[WD_ILP];
+        if constexpr (LAB) {
+#pragma unroll
+          for (int u = 0; u < WD_ILP; ++u) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[u][k] = lab[u].c[k] == (unsigned)c ? 1.f : 0.f;
+            tv[u] = lab[u].t == (unsigned)c ? 1.f : 0.f;
+          }
+        } else {
+          const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + ((long long)n * C + c) * plane, plane_bytes);
+          const __amdgpu_buffer_rsrc_t rf = make_rsrc(fixed + ((long long)n * C + c) * ovox + vb + j0 * TPB, fbytes);
+#pragma unroll
+          for (int u = 0; u < WD_ILP; ++u) {
+            gather8_b(rx, q[u], v[u]);
+            tv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, 4 * (tid + u * TPB), 0, 0));
+          }
         }
 #pragma unroll
         for (int u = 0; u < WD_ILP; ++u) {
@@ -739,6 +811,48 @@ __global__ __launch_bounds__(TPB) void warp_dice_grad_kernel(
     __syncthreads();
     unstage_rows(dgrid + ((long long)n * ovox + vb) * 3, cnt, sg, tid);
   }
+}
+
+// x (N, C, V) floats -> lab (N, V) bytes when every voxel is exactly one-hot (one channel == 1.0f, all others == 0.0f);
+// any other voxel clears *ok (preset to 1 by the launcher; same-value stores from many threads)
+__global__ __launch_bounds__(TPB) void onehot_to_labels_kernel(const float* __restrict__ x, int C, long long V,
+                                                               unsigned char* __restrict__ lab, int* __restrict__ ok) {
+  const int n = blockIdx.y;
+  const float* xn = x + (long long)n * C * V;
+  unsigned char* ln = lab + (long long)n * V;
+  // 16-byte loads need every channel plane (and the byte map) aligned: V % 4 == 0 and aligned bases; else the scalar loop
+  const bool vec = (V & 3) == 0 && ((reinterpret_cast<unsigned long long>(x) & 15) == 0) &&
+                   ((reinterpret_cast<unsigned long long>(lab) & 3) == 0);
+  const long long V4 = vec ? (V >> 2) : 0;
+  bool good = true;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < V4; i += (long long)gridDim.x * TPB) {
+    int ones[4] = {0, 0, 0, 0}, which[4] = {0, 0, 0, 0};
+    bool clean = true;
+    for (int c = 0; c < C; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(xn + (long long)c * V + 4 * i);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (vv[j] == 1.f) { ++ones[j]; which[j] = c; }
+        else if (vv[j] != 0.f) clean = false;            // (NaN lands here too)
+      }
+    }
+    good = good && clean && ones[0] == 1 && ones[1] == 1 && ones[2] == 1 && ones[3] == 1;
+    *reinterpret_cast<unsigned*>(ln + 4 * i) = (unsigned)which[0] | ((unsigned)which[1] << 8) | ((unsigned)which[2] << 16) |
+                                               ((unsigned)which[3] << 24);
+  }
+  if (!vec) {                                            // unaligned shapes: one voxel per thread
+    for (long long v = (long long)blockIdx.x * TPB + threadIdx.x; v < V; v += (long long)gridDim.x * TPB) {
+      int ones = 0, which = 0;
+      for (int c = 0; c < C; ++c) {
+        const float t = xn[(long long)c * V + v];
+        if (t == 1.f) { ++ones; which = c; } else if (t != 0.f) good = false;
+      }
+      good = good && ones == 1;
+      ln[v] = (unsigned char)which;
+    }
+  }
+  if (!good) *ok = 0;
 }
 
 // scatter-add backward wrt the sampled volume (not on the training hot path: the volumes are data;
@@ -1090,8 +1204,11 @@ KMH_API int kmh_dice_sums(const float* pred, const float* target, int R, long lo
  * scripts/train.py:146-164).  ws: kmh_reduce_ws_bytes().  Returns KMH_EINVAL (-22) when the lane-contiguous kernel does
  * not apply (W < 2, a plane of >= 2^31 voxels, C > 128): the caller then uses the separate entry points. */
 KMH_API int kmh_warp_dice_sums(const float* x, const float* grid, const float* fixed, float* sums, int N, int C, int D,
-                               int H, int W, int Do, int Ho, int Wo, void* ws, void* stream) {
+                               int H, int W, int Do, int Ho, int Wo, const unsigned char* lab_x,
+                               const unsigned char* lab_fixed, const int* gate, void* ws, void* stream) {
   if (N <= 0 || C <= 0 || C > WD_MAXC || !lane_contiguous_ok(D, H, W) || (long long)D * H * W >= (1ll << 30)) return -22;
+  const bool labs = lab_x && lab_fixed && gate;
+  if (!labs && (lab_x || lab_fixed || gate)) return -22;            // all three or none
   const long long ovox = (long long)Do * Ho * Wo;
   const int nchunk = ceil_div(ovox, (long long)TPB * PASSES);
   long long nb = 65536 / ((long long)N * C);          // partial (N, nb, C, 3) doubles inside the reduction workspace
@@ -1101,19 +1218,34 @@ KMH_API int kmh_warp_dice_sums(const float* x, const float* grid, const float* f
   const int per_n = (capa / N) & ~7;                 // a multiple of 8 per sample row: blockIdx.x % 8 is the XCD
   if (nb > per_n) nb = per_n < 8 ? 8 : per_n;
   hipStream_t s = (hipStream_t)stream;
-  static const int ilp = getenv("KMH_WD_ILP_A") ? atoi(getenv("KMH_WD_ILP_A")) : 4;        // A/B switch (tools/bench_sampler.py)
-  static const int uc = getenv("KMH_WD_UC") ? atoi(getenv("KMH_WD_UC")) : 1;
+  static const int ilp = getenv("KMH_WD_ILP_A") ? atoi(getenv("KMH_WD_ILP_A")) : 4;        // A/B switch (tools/bench_warp_dice.py)
   const dim3 g((unsigned)nb, N);
-  if (ilp == 4 && uc == 1)
-    warp_dice_sums_kernel<4, 1><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk);
-  else if (ilp == 4)
-    warp_dice_sums_kernel<4, 2><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk);
-  else if (uc == 1)
-    warp_dice_sums_kernel<2, 1><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk);
+  // with label maps: BOTH variants are launched with the same grid; the device flag lets exactly one of them work
+  if (labs)
+    warp_dice_sums_kernel<4, 1, true><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk, lab_x,
+                                                         lab_fixed, gate);
+  if (ilp == 4)
+    warp_dice_sums_kernel<4, 1><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk, nullptr, nullptr,
+                                                  labs ? gate : nullptr);
   else
-    warp_dice_sums_kernel<2, 2><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk);
+    warp_dice_sums_kernel<2, 1><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk, nullptr, nullptr,
+                                                  labs ? gate : nullptr);
   const int total = N * C * 3;
   warp_dice_final_kernel<<<ceil_div(total, TPB / kWave), TPB, 0, s>>>((const double*)ws, (int)nb, C, total, sums);
+  return KMH_LAUNCH_CHECK();
+}
+
+/* x (N, C, V) floats -> lab (N, V) bytes = the channel that holds the 1 when every voxel is exactly one-hot; ok[0] (device
+ * int, this call only ever CLEARS it: preset it to 1, chain several tensors onto one flag) stays 1 iff that held
+ * everywhere.  What keymorph/utils.py:200-240 (one_hot / one_hot_subsampled_pair) and nearest-sampled augmentation
+ * (keymorph/augmentation.py:160-163) produce is exactly one-hot; a soft segmentation clears the flag and the Dice kernels
+ * then read the float tensors.  C <= 255. */
+KMH_API int kmh_onehot_to_labels(const float* x, int N, int C, long long V, unsigned char* lab, int* ok, void* stream) {
+  if (N <= 0 || C <= 0 || C > 255 || V <= 0) return -22;
+  long long nb = (V / 4 + TPB - 1) / TPB;
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  onehot_to_labels_kernel<<<dim3((unsigned)nb, N), TPB, 0, (hipStream_t)stream>>>(x, C, V, lab, ok);
   return KMH_LAUNCH_CHECK();
 }
 
@@ -1121,8 +1253,11 @@ KMH_API int kmh_warp_dice_sums(const float* x, const float* grid, const float* f
  * den = P + T + 1 from kmh_warp_dice_sums): dgrid[n, v, :] = sum_c (ca t + cb p) * d p / d grid, p recomputed from x.
  * Autograd of keymorph/loss_ops.py:16-63 through keymorph/utils.py:14-21 in one pass. */
 KMH_API int kmh_warp_dice_bwd_grid(const float* x, const float* grid, const float* fixed, const float* ca, const float* cb,
-                                   float* dgrid, int N, int C, int D, int H, int W, int Do, int Ho, int Wo, void* stream) {
+                                   float* dgrid, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
+                                   const unsigned char* lab_x, const unsigned char* lab_fixed, const int* gate, void* stream) {
   if (N <= 0 || C <= 0 || !lane_contiguous_ok(D, H, W) || (long long)D * H * W >= (1ll << 30)) return -22;
+  const bool labs = lab_x && lab_fixed && gate;
+  if (!labs && (lab_x || lab_fixed || gate)) return -22;
   const long long ovox = (long long)Do * Ho * Wo;
   const int nchunk = ceil_div(ovox, (long long)TPB * PASSES);
   static const int cap = getenv("KMH_WD_BLOCKS") ? atoi(getenv("KMH_WD_BLOCKS")) : 768;
@@ -1130,15 +1265,17 @@ KMH_API int kmh_warp_dice_bwd_grid(const float* x, const float* grid, const floa
   int per_n = (cap / N) & ~7;
   if (per_n < 8) per_n = 8;
   int nb = nchunk < per_n ? nchunk : per_n;
-  static const int uc = getenv("KMH_WD_UC") ? atoi(getenv("KMH_WD_UC")) : 1;
   const dim3 g(nb, N);
   hipStream_t s = (hipStream_t)stream;
+  if (labs)
+    warp_dice_grad_kernel<2, 1, true><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk, lab_x,
+                                                         lab_fixed, gate);
   if (ilp == 4)
-    warp_dice_grad_kernel<4, 1><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk);
-  else if (uc == 1)
-    warp_dice_grad_kernel<2, 1><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk);
+    warp_dice_grad_kernel<4, 1><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk, nullptr, nullptr,
+                                                  labs ? gate : nullptr);
   else
-    warp_dice_grad_kernel<2, 2><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk);
+    warp_dice_grad_kernel<2, 1><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk, nullptr, nullptr,
+                                                  labs ? gate : nullptr);
   return KMH_LAUNCH_CHECK();
 }
 

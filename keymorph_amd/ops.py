@@ -6,6 +6,8 @@ eager/PyTorch fallback -- a CPU tensor or a missing library raises.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -239,7 +241,11 @@ def dice_rows(pred: Tensor, target: Tensor) -> Tensor:
 class _WarpDiceRows(torch.autograd.Function):
     """Dice rows of align_img(grid, x) against `fixed` WITHOUT the warped tensor: one pass for the three sums per (n, c)
     (kmh_warp_dice_sums), one pass for d/d(grid) (kmh_warp_dice_bwd_grid; the warp is recomputed, nothing is stored).
-    scripts/train.py:146-164 with loss_fn == "dice"; keymorph/utils.py:14-21 + keymorph/loss_ops.py:16-63."""
+    scripts/train.py:146-164 with loss_fn == "dice"; keymorph/utils.py:14-21 + keymorph/loss_ops.py:16-63.
+    Both segmentations are first checked for being exactly one-hot ON THE DEVICE (kmh_onehot_to_labels: one streaming
+    read each, writes byte label maps + a flag); when they are -- one_hot() of a label map, nearest-sampled augmentation --
+    the two passes read one byte per voxel instead of 4 C; a soft segmentation clears the flag and the same launches read
+    the float tensors.  No host synchronisation decides; the results are bit-identical either way."""
 
     @staticmethod
     def forward(ctx, x, grid, fixed):
@@ -249,12 +255,21 @@ class _WarpDiceRows(torch.autograd.Function):
         _, Do, Ho, Wo, _ = grid.shape
         assert fixed.shape == (N, C, Do, Ho, Wo), "the fixed segmentation must have the warped tensor's shape"
         sums = torch.empty((N * C, 3), dtype=torch.float32, device=x.device)
+        labx = labf = gate = None
+        if C <= 255 and not os.environ.get("KEYMORPH_DICE_NO_LABELS"):
+            labx = torch.empty((N, D * H * W), dtype=torch.uint8, device=x.device)
+            labf = torch.empty((N, Do * Ho * Wo), dtype=torch.uint8, device=x.device)
+            gate = torch.ones(1, dtype=torch.int32, device=x.device)
+            check(lib.kmh_onehot_to_labels(_p(x), N, C, D * H * W, _p(labx), _p(gate), _stream()), "kmh_onehot_to_labels")
+            check(lib.kmh_onehot_to_labels(_p(fixed), N, C, Do * Ho * Wo, _p(labf), _p(gate), _stream()),
+                  "kmh_onehot_to_labels")
         if _lib.profiler.enabled:      # grid 12 B + C * (gathered volume 4 + fixed 4) per output voxel
             _lib.profiler.meta = {"bytes": float(N * Do * Ho * Wo) * (12 + 8 * C)}
-        check(lib.kmh_warp_dice_sums(_p(x), _p(grid), _p(fixed), _p(sums), N, C, D, H, W, Do, Ho, Wo,
-                                     _p(_reduce_ws(x.device)), _stream()), "kmh_warp_dice_sums")
+        check(lib.kmh_warp_dice_sums(_p(x), _p(grid), _p(fixed), _p(sums), N, C, D, H, W, Do, Ho, Wo, _p(labx), _p(labf),
+                                     _p(gate), _p(_reduce_ws(x.device)), _stream()), "kmh_warp_dice_sums")
         num = 2 * sums[:, 0] + 1
         den = sums[:, 1] + sums[:, 2] + 1
+        ctx.labels = (labx, labf, gate)
         ctx.save_for_backward(x, grid, fixed, num, den)
         return (1 - num / den).view(N, C)
 
@@ -262,6 +277,7 @@ class _WarpDiceRows(torch.autograd.Function):
     def backward(ctx, g):
         lib = _lib.load()
         x, grid, fixed, num, den = ctx.saved_tensors
+        labx, labf, gate = ctx.labels
         N, C, D, H, W = x.shape
         _, Do, Ho, Wo, _ = grid.shape
         g = _prep(g).reshape(-1)
@@ -271,7 +287,7 @@ class _WarpDiceRows(torch.autograd.Function):
         if _lib.profiler.enabled:      # the same reads + 12 B of grid gradient
             _lib.profiler.meta = {"bytes": float(N * Do * Ho * Wo) * (24 + 8 * C)}
         check(lib.kmh_warp_dice_bwd_grid(_p(x), _p(grid), _p(fixed), _p(ca), _p(cb), _p(dgrid), N, C, D, H, W, Do, Ho, Wo,
-                                         _stream()), "kmh_warp_dice_bwd_grid")
+                                         _p(labx), _p(labf), _p(gate), _stream()), "kmh_warp_dice_bwd_grid")
         return None, dgrid, None
 
 

@@ -150,7 +150,7 @@ def test_dice_golden_and_grad():
 
 
 @pytest.mark.parametrize("shape,C,N", [((9, 10, 11), 3, 2), ((16, 16, 16), 14, 1), ((5, 33, 70), 5, 2), ((24, 20, 50), 1, 1)])
-def test_fused_warp_dice_vs_oracle_and_unfused(shape, C, N):
+def test_fused_warp_dice_vs_oracle_and_unfused(shape, C, N, monkeypatch):
     """loss_ops.warp_dice_loss == DiceLoss()(align_img(grid, seg_m), seg_f) (scripts/train.py:146-164) in value and in
     d/d(grid): against the oracle's autograd (keymorph/utils.py:14-21 + loss_ops.py:16-63 restated) and against this
     package's unfused three-launch route; one-hot and soft segmentations, ragged sizes, grids that leave the volume
@@ -185,6 +185,15 @@ def test_fused_warp_dice_vs_oracle_and_unfused(shape, C, N):
             scale = max(float(gr.grad.abs().max()), 1e-6)      # (C = 1 one-hot: a constant volume, zero gradient)
             close(gh.grad, gr.grad, 2e-5 * scale, 1e-4)
             close(gh.grad, gu.grad, 2e-6 * scale, 1e-5)
+            if not soft and not kw:
+                # exactly one-hot inputs took the label-map kernels (one byte per voxel): the dense kernels, forced by
+                # KEYMORPH_DICE_NO_LABELS, must give the same bits
+                monkeypatch.setenv("KEYMORPH_DICE_NO_LABELS", "1")
+                gd = grid.to(DEV).requires_grad_(True)
+                dense = loss_ops.warp_dice_loss(gd, seg_m.to(DEV), seg_f.to(DEV))
+                dense.backward()
+                monkeypatch.delenv("KEYMORPH_DICE_NO_LABELS")
+                assert torch.equal(dense, out) and torch.equal(gd.grad, gh.grad)
 
 
 def test_fused_warp_dice_falls_back_when_the_moving_segmentation_needs_a_gradient():

@@ -40,10 +40,17 @@ def timeit(fn, n=10, reps=3):
 
 V = N * S ** 3
 tag = " ".join(f"{k}={os.environ[k]}" for k in ("KMH_WD_ILP_A", "KMH_WD_ILP_B", "KMH_WD_BLOCKS") if k in os.environ)
-t = timeit(lambda: lib.kmh_warp_dice_sums(p(x), p(grid), p(f), p(sums), N, C, S, S, S, S, S, S, p(ws), st))
-print(f"[{tag}] warp_dice_sums     {t:7.3f} ms  {V*(12+8*C)/t/1e9:7.2f} TB/s ({12+8*C} B/voxel)  checksum {float(sums.double().sum()):.3f}")
-t = timeit(lambda: lib.kmh_warp_dice_bwd_grid(p(x), p(grid), p(f), p(ca), p(cb), p(dg), N, C, S, S, S, S, S, S, st))
-print(f"[{tag}] warp_dice_bwd_grid {t:7.3f} ms  {V*(24+8*C)/t/1e9:7.2f} TB/s ({24+8*C} B/voxel)  checksum {float(dg.double().abs().sum()):.3f}")
+labx = torch.empty(N, S ** 3, dtype=torch.uint8, device=dev); labf = torch.empty_like(labx)
+gate = torch.ones(1, dtype=torch.int32, device=dev)
+t = timeit(lambda: (lib.kmh_onehot_to_labels(p(x), N, C, S ** 3, p(labx), p(gate), st),
+                    lib.kmh_onehot_to_labels(p(f), N, C, S ** 3, p(labf), p(gate), st)))
+print(f"[{tag}] onehot_to_labels x 2   {t:7.3f} ms  {2*V*4*C/t/1e9:7.2f} TB/s ({8*C} B/voxel read)  gate {int(gate)}")
+for name, lx, lf, gt in (("labels", labx, labf, gate), ("dense ", None, None, None)):
+    pl = (lambda t_: 0 if t_ is None else t_.data_ptr())
+    t = timeit(lambda: lib.kmh_warp_dice_sums(p(x), p(grid), p(f), p(sums), N, C, S, S, S, S, S, S, pl(lx), pl(lf), pl(gt), p(ws), st))
+    print(f"[{tag}] {name} warp_dice_sums     {t:7.3f} ms  {V*(12+8*C)/t/1e9:7.2f} TB/s of the dense {12+8*C} B/voxel  checksum {float(sums.double().sum()):.3f}")
+    t = timeit(lambda: lib.kmh_warp_dice_bwd_grid(p(x), p(grid), p(f), p(ca), p(cb), p(dg), N, C, S, S, S, S, S, S, pl(lx), pl(lf), pl(gt), st))
+    print(f"[{tag}] {name} warp_dice_bwd_grid {t:7.3f} ms  {V*(24+8*C)/t/1e9:7.2f} TB/s of the dense {24+8*C} B/voxel  checksum {float(dg.double().abs().sum()):.3f}")
 if not tag:
     out = torch.empty_like(x)
     t = timeit(lambda: lib.kmh_grid_sample3d_fwd(p(x), p(grid), p(out), N, C, S, S, S, S, S, S, 0, st))
