@@ -379,7 +379,8 @@ def main():
                       "dice_loss": dice_loss,
                       "dice_config": f"loss_fn=dice: ({a.pairs_per_gpu},14,{a.size}^3) one-hot segmentations, align_img "
                                      f"(bilinear) + DiceLoss fwd+bwd as the fused loss_ops.warp_dice_loss (the warped "
-                                     f"segmentation is never stored) in place of warp+MSE, {a.dice} timed step(s)"})
+                                     f"segmentation is never stored; both one-hot tensors are re-checked on the device "
+                                     f"EVERY step and then read as one byte per voxel) in place of warp+MSE, {a.dice} timed step(s)"})
         del seg_f, seg_m
     if a.also_f32 > 0 and a.conv != "f32":      # the same step on the exact fp32 MFMA, in the same driver run
         backbone_ops.set_conv_mode("f32")
