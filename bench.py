@@ -208,12 +208,12 @@ def roofline(mode, conv_tf):
             "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": src}
 
 
-def cpu_baseline(threads, seconds, big_size=0, big_kp=512):
+def cpu_baseline(threads, seconds):
     """BASELINE.json configs[0] measured, not extrapolated: the oracle (CPU restatement, same ATen ops as the
     reference; pinned against the reference's own outputs for exactly this pair, tests/test_cfg1_gpu.py) on the host
     cores -- the example_data_half pair at 128^3 (intensity = label / 13; tests/golden/
     cfg1_example_half_128.npz), 128 keypoints, affine aligner, TruncatedUNet3D(f_maps 32), fwd + bwd, MSE.
-    One warm-up + >= 2 timed pairs, bounded by `seconds`."""
+    One warm-up + >= 2 timed pairs, bounded by `seconds`.  (The full-size oracle run is cpu_baseline_at_size below.)"""
     import numpy as np
     import platform
     from oracle import keymorph_oracle as O
@@ -248,25 +248,6 @@ def cpu_baseline(threads, seconds, big_size=0, big_kp=512):
         n += 1
     dt = (time.time() - t0) / n
     big = None
-    if big_size:
-        avail = 0.0
-        try:
-            for line in open("/proc/meminfo"):
-                if line.startswith("MemAvailable"):
-                    avail = float(line.split()[1]) / 2 ** 20
-        except OSError:
-            pass
-        if avail >= 96:
-            # BASELINE configs[1] shape on the host: the same synthetic pair recipe as the GPU legs (blob volume and an
-            # affine-warped copy, generated on the CPU by the oracle), 512 keypoints, affine aligner, fwd + bwd, MSE;
-            # ONE pair, no warm-up (the process is warm from the 128^3 sample; a pair is tens of seconds).  The result
-            # is KEPT: main() runs the HIP path on the same pair and weights and reports `parity_at_size`.
-            from tests.oracle_at_size import oracle_pair
-            ref = oracle_pair(big_size, big_kp, threads=nthreads, tt="affine", seed=100, sd_seed=23)
-            big = {"seconds_per_pair": ref["seconds"], "forward_seconds": ref["forward_seconds"], "size": big_size,
-                   "keypoints": big_kp, "mem_available_gib": avail, "ref": ref}
-        else:
-            big = {"skipped": f"only {avail:.0f} GiB of host RAM available (needs ~50, wants 96)"}
     cpu = platform.processor() or ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -279,6 +260,28 @@ def cpu_baseline(threads, seconds, big_size=0, big_kp=512):
           file=sys.stderr)
     return {"seconds_per_pair": dt, "pairs": n, "threads": nthreads, "host_cores": ncores, "cpu_model": cpu, "data": data,
             "big": big}
+
+
+def cpu_baseline_at_size(size, keypoints, threads):
+    """BASELINE configs[1] shape on the host: the same synthetic pair recipe as the GPU legs (blob volume and an
+    affine-warped copy, generated on the CPU by the oracle), 512 keypoints, affine aligner, fwd + bwd, MSE; ONE pair, cold
+    (a pair is two minutes), in a CHILD process with its own thread pool (tests/oracle_at_size.py).  The result is KEPT:
+    the HIP path then runs on the same pair and weights -> `parity_at_size`."""
+    avail = 0.0
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                avail = float(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    if avail < 96:
+        return {"skipped": f"only {avail:.0f} GiB of host RAM available (needs ~50, wants 96)"}
+    from tests.oracle_at_size import oracle_pair
+    ncores = os.cpu_count()
+    nthreads = ncores if threads <= 0 else min(threads, ncores)
+    ref = oracle_pair(size, keypoints, threads=nthreads, tt="affine", seed=100, sd_seed=23)
+    return {"seconds_per_pair": ref["seconds"], "forward_seconds": ref["forward_seconds"], "size": size,
+            "keypoints": keypoints, "mem_available_gib": avail, "ref": ref}
 
 
 def main():
@@ -671,10 +674,10 @@ def main():
         }
         out.update(extra)
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
-            c = cpu_baseline(a.cpu_threads, a.cpu_seconds, a.size if a.cpu_256 else 0, a.keypoints)
-            vox_ratio = (a.size / 128) ** 3
-            big = c.get("big") or {}
-            measured = "seconds_per_pair" in big
+            # order matters: the full-size oracle (child process) and the HIP comparison first, the in-process 128^3 sample
+            # (which changes this process's intra-op thread count) last
+            big = cpu_baseline_at_size(a.size, a.keypoints, a.cpu_threads) if a.cpu_256 else {}
+            par_out = None
             if "ref" in big:            # oracle result at the metric's size vs the HIP path on the same pair and weights
                 from tests.oracle_at_size import compare_with_hip
                 try:
@@ -687,9 +690,14 @@ def main():
                                              "tail (the ill-conditioned part: tests/oracle_at_size.py)")
                     par["what"] = ("HIP path (default arithmetic) vs the CPU oracle's forward and AUTOGRAD backward on the same "
                                    f"{par['size']}^3 pair, seeded weights (23): max-abs differences; gradients relative L2")
-                    out["parity_at_size"] = par
+                    par_out = par
                 except Exception as e:      # noqa: BLE001
-                    out["parity_at_size"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    par_out = {"error": f"{type(e).__name__}: {e}"[:300]}
+            c = cpu_baseline(a.cpu_threads, a.cpu_seconds)
+            vox_ratio = (a.size / 128) ** 3
+            if par_out is not None:
+                out["parity_at_size"] = par_out
+            measured = "seconds_per_pair" in big
             # `value` is in the headline's units AT the headline's volume size and keypoint count: the measured
             # size^3 / 512-keypoint pair when the host could run it, else the 128^3 sample scaled by the voxel ratio
             value = 1.0 / big["seconds_per_pair"] if measured else 1.0 / (c["seconds_per_pair"] * vox_ratio)

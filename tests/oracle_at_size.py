@@ -30,10 +30,29 @@ def _tail(O, pf, pm, img_f, img_m, tt):
     return r, img_a.detach(), mse.detach(), dpf, dpm
 
 
-def oracle_pair(size, keypoints, threads=32, tt="affine", seed=100, sd_seed=23):
+def oracle_pair(size, keypoints, threads=32, tt="affine", seed=100, sd_seed=23, in_subprocess=True):
     """One synthetic pair (keymorph_amd.synthetic's recipe evaluated with the ORACLE's sampler on the CPU), seeded weights
     of TruncatedUNet3D(1, K, f_maps 32, 4 levels, 1 truncated), forward + MSE + autograd backward on the host.
-    Returns CPU tensors and timings; ~2 min and ~50 GB of host RAM at 256^3."""
+    Returns CPU tensors and timings; ~2 min and ~50 GB of host RAM at 256^3.
+    in_subprocess (default): the run happens in a CHILD interpreter with its own thread pool and the result comes back
+    through a file.  Changing torch's intra-op thread count inside a long-lived process is not safe to rely on: with the
+    oracle run in-process, a later CPU `torch.linalg.solve` of the same pytest session returned a wrong answer on the MI355X
+    box (tests/test_ops_gpu.py::test_tps_fit_vs_fp64[200-1.0], only after this test), and the child also returns its 50 GB."""
+    if in_subprocess:
+        import os
+        import subprocess
+        import sys
+        import tempfile
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "oracle_pair.pt")
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads or os.cpu_count()), MKL_NUM_THREADS=str(threads or os.cpu_count()))
+            code = (f"import sys; sys.path.insert(0, {root!r}); import torch; from tests.oracle_at_size import oracle_pair; "
+                    f"torch.save(oracle_pair({size}, {keypoints}, {threads}, {tt!r}, {seed}, {sd_seed}, in_subprocess=False), {out!r})")
+            r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("the oracle child process failed:\n" + r.stderr[-3000:])
+            return torch.load(out, weights_only=False)
     from keymorph_amd import synthetic
     from oracle import keymorph_oracle as O
     if threads:
