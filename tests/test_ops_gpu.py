@@ -223,7 +223,10 @@ def test_affine_grid(shape):
     close(Mh.grad, Mr.grad, 1e-3, 1e-4)
 
 
-@pytest.mark.parametrize("T_,shape", [(16, (6, 7, 8)), (64, (12, 10, 9)), (130, (8, 8, 8))])
+# (the last two shapes take the row-hoisted evaluators with the weighted sums on the 4x4x1 MFMA: whole 1024-voxel blocks and
+# W % 4 == 0 forward, W % 256 == 0 backward; T = 130 leaves idle keypoint lanes in the backward's MFMA blocks)
+@pytest.mark.parametrize("T_,shape", [(16, (6, 7, 8)), (64, (12, 10, 9)), (130, (8, 8, 8)), (64, (8, 16, 16)), (130, (2, 4, 256)),
+                                      (512, (4, 8, 256))])
 def test_tps_grid_given_theta(T_, shape):
     g = gen(8)
     ctrl = torch.rand(2, T_, 3, generator=g) * 1.6 - 0.8
