@@ -111,14 +111,7 @@ __global__ __launch_bounds__(192) void affine_grid_bwd_final(const double* __res
 // ROWQ (implicit grid with W % VPT == 0): the lane's VPT voxels are consecutive in x, so (cz - z)^2 + (cy - y)^2 + 1e-6 --
 // the inner two links of tps_d2's fma chain -- is ONE scalar per keypoint instead of VPT/2 packed evaluations: 4 plain
 // VALU replace 8 packed ones of the 22 per keypoint and voxel quad, bit-identical results (the chain's order is kept).
-// MF (round 4, with ROWQ): the three weighted sums out_d += U w_d leave the VALU for the otherwise idle matrix pipe.
-// v_mfma_f32_4x4x1_16b_f32 is 16 independent 4x4 outer products D[r][j] += A[r] B[j] per wave, lane l of block l / 4
-// supplying A[l % 4] and B[l % 4] and receiving column l % 4 in its four result registers: with A = (w_z, w_y, w_x, 0) dealt
-// over the four lanes of every block and B = this lane's own U, register r of lane l becomes w_r U_l -- exactly the lane's three
-// fused multiply-adds (an fp32 MFMA is bit-for-bit an fmaf: MI355X_MICROARCH.md), at 8 matrix-pipe cycles per voxel and wave
-// while the VALU computes the next U.  fp32 MFMA and packed fp32 VALU have the same peak rate on this chip and run side by side.
-typedef float kmh_f4v __attribute__((ext_vector_type(4)));
-template <bool EXPLICIT_POINTS, bool ROWQ = false, bool MF = false>
+template <bool EXPLICIT_POINTS, bool ROWQ = false>
 __global__ __launch_bounds__(TPB) void tps_eval_fwd_kernel(const float* __restrict__ theta,
                                                            const float* __restrict__ ctrl,
                                                            const float* __restrict__ pts,
@@ -161,34 +154,7 @@ __global__ __launch_bounds__(TPB) void tps_eval_fwd_kernel(const float* __restri
     qz[h] = kmh_f2{pz[2 * h], pz[2 * h + 1]}; qy[h] = kmh_f2{py[2 * h], py[2 * h + 1]}; qx[h] = kmh_f2{px[2 * h], px[2 * h + 1]};
     az2[h] = ay2[h] = ax2[h] = kmh_f2{0.f, 0.f};
   }
-  if constexpr (ROWQ && MF && !EXPLICIT_POINTS) {
-    const float pz0 = pz[0], py0 = py[0];
-    kmh_f4v acc[VPT];
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) acc[i] = kmh_f4v{0.f, 0.f, 0.f, 0.f};
-    const float* swf = reinterpret_cast<const float*>(sw) + (threadIdx.x & 3);      // this lane's component of every weight row
-#pragma unroll 4
-    for (int t = 0; t < T; ++t) {
-      const float4 c = sc[t];
-      const float wa = swf[4 * t];                                  // (w_z, w_y, w_x, 0)[lane % 4] * ln 2
-      const float dzs = c.x - pz0, dys = c.y - py0;
-      const float zy = fmaf(dys, dys, fmaf(dzs, dzs, 1e-6f));
-      const kmh_f2 zy2 = {zy, zy};
-#pragma unroll
-      for (int h = 0; h < VPT / 2; ++h) {
-        const kmh_f2 dx = c.z - qx[h];
-        const kmh_f2 u = tps_u2_from_d2(__builtin_elementwise_fma(dx, dx, zy2));
-        acc[2 * h] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa, u.x, acc[2 * h], 0, 0, 0);
-        acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa, u.y, acc[2 * h + 1], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < VPT / 2; ++h) {
-      az2[h] = kmh_f2{acc[2 * h][0], acc[2 * h + 1][0]};
-      ay2[h] = kmh_f2{acc[2 * h][1], acc[2 * h + 1][1]};
-      ax2[h] = kmh_f2{acc[2 * h][2], acc[2 * h + 1][2]};
-    }
-  } else if constexpr (ROWQ && !EXPLICIT_POINTS) {
+  if constexpr (ROWQ && !EXPLICIT_POINTS) {
     const float pz0 = pz[0], py0 = py[0];
 #pragma unroll 4
     for (int t = 0; t < T; ++t) {
@@ -255,9 +221,7 @@ constexpr int VCHUNK = 8192;       // voxels per block
 
 // ROWS (implicit grid with W % VSTAGE == 0): a stage's 256 voxels are one piece of ONE grid row, so dz, dy and the inner
 // links of the distance chain are per-stage constants of the lane's keypoints, and sum f dz = dz sum f (same for dy).
-// MF: the d(theta) sums aw_d += U g_d on the matrix pipe as in the forward (A = (g_z, g_y, g_x, 0) of the broadcast voxel dealt
-// over the lanes of a block, B = this lane's U for one of its two keypoints).
-template <bool EXPLICIT_POINTS, bool ROWS = false, bool MF = false>
+template <bool EXPLICIT_POINTS, bool ROWS = false>
 __global__ __launch_bounds__(BWD_TPB) void tps_eval_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ theta, const float* __restrict__ ctrl,
     const float* __restrict__ pts, float* __restrict__ partial /* (N, nchunk, T, 6) */, int T, int D,
@@ -282,7 +246,6 @@ __global__ __launch_bounds__(BWD_TPB) void tps_eval_bwd_kernel(
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) aw[d] = ac[d] = kmh_f2{0.f, 0.f};
-  [[maybe_unused]] kmh_f4v mw[KPT] = {kmh_f4v{0.f, 0.f, 0.f, 0.f}, kmh_f4v{0.f, 0.f, 0.f, 0.f}};      // MF: (z, y, x, -) per keypoint
   const float sz = lin_step(D), sy = lin_step(H), sx = lin_step(W);
   const long long vbeg = (long long)chunk * VCHUNK;
   long long vend = vbeg + VCHUNK;
@@ -313,7 +276,6 @@ __global__ __launch_bounds__(BWD_TPB) void tps_eval_bwd_kernel(
       const kmh_f2 eps2 = {1e-6f, 1e-6f};
       const kmh_f2 zy = __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, eps2));
       kmh_f2 fs = {0.f, 0.f};
-      [[maybe_unused]] const float* sgf = reinterpret_cast<const float*>(sg) + (threadIdx.x & 3);
 #pragma unroll 2
       for (int j = 0; j < cnt; ++j) {
         const float px = sp[j].z;
@@ -326,13 +288,7 @@ __global__ __launch_bounds__(BWD_TPB) void tps_eval_bwd_kernel(
         const kmh_f2 re = r + 1e-6f;
         L.x = __builtin_amdgcn_logf(re.x); L.y = __builtin_amdgcn_logf(re.y);
         const kmh_f2 u = d2 * L;
-        if constexpr (MF) {
-          const float ga = sgf[4 * j];                               // (g_z, g_y, g_x, 0)[lane % 4] of voxel j
-          mw[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ga, u.x, mw[0], 0, 0, 0);
-          mw[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ga, u.y, mw[1], 0, 0, 0);
-        } else {
-          aw[0] += u * gg.x; aw[1] += u * gg.y; aw[2] += u * gg.z;
-        }
+        aw[0] += u * gg.x; aw[1] += u * gg.y; aw[2] += u * gg.z;
         const kmh_f2 s = wz * gg.x + wy * gg.y + wx * gg.z;
         const kmh_f2 tt = rs * 1e-6f;
         const kmh_f2 f = s * __builtin_elementwise_fma(L, kmh_f2{2.f * 0.6931471805599453f, 2.f * 0.6931471805599453f},
@@ -364,10 +320,6 @@ __global__ __launch_bounds__(BWD_TPB) void tps_eval_bwd_kernel(
                                                      1.f - tt + tt * tt);
       ac[0] += f * dz; ac[1] += f * dy; ac[2] += f * dx;
     }
-  }
-  if constexpr (MF) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) aw[d] = kmh_f2{mw[0][d], mw[1][d]};
   }
 #pragma unroll
   for (int k = 0; k < KPT; ++k) {
@@ -554,11 +506,7 @@ KMH_API int kmh_tps_grid_fwd(const float* theta, const float* ctrl, float* out, 
   if (lds > 64 * 1024) return -22;
   static const bool no_rowq = getenv("KMH_TPS_NO_ROWQ") != nullptr;       // A/B switch (tools/prof_tps.py)
   const dim3 g(ceil_div(nvox, (long long)TPB * VPT), N);
-  static const bool no_mf = getenv("KMH_TPS_NO_MFMA") != nullptr;         // A/B switch: the weighted sums on the VALU
-  // (the early `return` of the last block's out-of-range lanes would leave an MFMA with a partial wave: whole quads only)
-  if (W % VPT == 0 && !no_rowq && !no_mf && nvox % ((long long)TPB * VPT) == 0)
-    tps_eval_fwd_kernel<false, true, true><<<g, TPB, lds, (hipStream_t)stream>>>(theta, ctrl, nullptr, out, T, D, H, W, nvox);
-  else if (W % VPT == 0 && !no_rowq)
+  if (W % VPT == 0 && !no_rowq)
     tps_eval_fwd_kernel<false, true><<<g, TPB, lds, (hipStream_t)stream>>>(theta, ctrl, nullptr, out, T, D, H, W, nvox);
   else
     tps_eval_fwd_kernel<false, false><<<g, TPB, lds, (hipStream_t)stream>>>(theta, ctrl, nullptr, out, T, D, H, W, nvox);
@@ -597,11 +545,7 @@ KMH_API int kmh_tps_grid_bwd(const float* dgrid, const float* theta, const float
   double* affp = (double*)((char*)ws + off);
   float* dmat = (float*)((char*)affp + (size_t)N * AFF_BWD_BLOCKS * 12 * sizeof(double));
   static const bool no_rowq = getenv("KMH_TPS_NO_ROWQ") != nullptr;
-  static const bool no_mf = getenv("KMH_TPS_NO_MFMA") != nullptr;
-  if (W % VSTAGE == 0 && !no_rowq && !no_mf)
-    tps_eval_bwd_kernel<false, true, true><<<dim3(nchunk, ktiles, N), BWD_TPB, 0, s>>>(dgrid, theta, ctrl, nullptr, partial,
-                                                                                     T, D, H, W, nvox, nchunk);
-  else if (W % VSTAGE == 0 && !no_rowq)
+  if (W % VSTAGE == 0 && !no_rowq)
     tps_eval_bwd_kernel<false, true><<<dim3(nchunk, ktiles, N), BWD_TPB, 0, s>>>(dgrid, theta, ctrl, nullptr, partial,
                                                                                T, D, H, W, nvox, nchunk);
   else
