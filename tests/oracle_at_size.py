@@ -201,3 +201,39 @@ def extra_legs(ref, km, f, m, dev, samples=4096):
         got_plain = float(loss_ops.DiceLoss()(utils.align_img(aff, seg_m.to(dev)), seg_f.to(dev)))
     out.update({"dice_oracle": want, "dice_fused": abs(got_fused - want), "dice_unfused": abs(got_plain - want)})
     return out
+
+
+def _child(call, threads):
+    """evaluate `tests.oracle_at_size.<call>` in a child interpreter with its own thread pool; returns what it returned"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "result.pt")
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        code = (f"import sys; sys.path.insert(0, {root!r}); import torch; torch.set_num_threads({threads}); "
+                f"import tests.oracle_at_size as M; torch.save(M.{call}, {out!r})")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("the oracle child process failed:\n" + r.stderr[-3000:])
+        return torch.load(out, weights_only=False)
+
+
+def oracle_convnet(size, keypoints, sd_seed=77, vol_seed=11, cot_seed=4, threads=32, in_subprocess=True):
+    """ConvNet(instance norm) of keymorph/net.py:7-36 on one blob volume, center of mass, and the autograd gradients of
+    sum(keypoints * cot) with respect to every weight -- on the host, in a child process by default."""
+    if in_subprocess:
+        return _child(f"oracle_convnet({size}, {keypoints}, {sd_seed}, {vol_seed}, {cot_seed}, {threads}, False)", threads)
+    from keymorph_amd import synthetic
+    from oracle import keymorph_oracle as O
+    from tests.util import convnet_shapes
+    sd = {k: v.requires_grad_(True) for k, v in seeded_state_dict(convnet_shapes(keypoints), sd_seed).items()}
+    x = synthetic.blob_volume(size, vol_seed, torch.device("cpu"))
+    y = O.convnet_forward(sd, x, "instance")
+    pts = O.center_of_mass(y, "ij")
+    cot = torch.randn(pts.shape, generator=torch.Generator().manual_seed(cot_seed))
+    (pts * cot).sum().backward()
+    return {"x": x, "sd": {k: v.detach() for k, v in sd.items()}, "y": y.detach(), "pts": pts.detach(), "cot": cot,
+            "grads": {k: v.grad.detach() for k, v in sd.items()}}

@@ -316,6 +316,41 @@ def test_convnet_lazy_instance_norm_equals_block_by_block(shape, N, monkeypatch)
         assert float((a - r).norm() / (r.norm() + 1e-30)) < 3e-2, (k, "lazy vs oracle")
 
 
+def test_convnet_instance_128_vs_oracle_forward_and_autograd():
+    """The reference's other backbone at a size its blocks are not toys (keymorph/net.py:7-36; 128^3, 64 keypoints, the
+    lazy-InstanceNorm route): keypoint logits and center-of-mass keypoints against the oracle, and every weight gradient of
+    a keypoint-space loss against the oracle's autograd (host: ~20 s, in a child process: tests/oracle_at_size.py)."""
+    from keymorph_amd import ops as kops
+    from keymorph_amd.net import ConvNet
+    from tests.oracle_at_size import oracle_convnet
+    Kc, S = 64, 128
+    ref = oracle_convnet(S, Kc)
+    net = ConvNet(3, 1, Kc, "instance")
+    net.load_state_dict(ref["sd"], strict=True)
+    net = net.to(DEV).train()
+    y = net(ref["x"].to(DEV))
+    pts = kops.com3d(y)
+    (pts * ref["cot"].to(DEV)).sum().backward()
+    scale = float(ref["y"].abs().max())
+    e_y = float((y.detach().cpu() - ref["y"]).abs().max()) / scale
+    e_p = float((pts.detach().cpu() - ref["pts"]).abs().max())
+    num = den = 0.0
+    worst = ("", 0.0)
+    for k, p in net.named_parameters():
+        if k.endswith("conv.bias"):
+            continue                                   # exactly zero under InstanceNorm (round-off in the oracle)
+        a, r = p.grad.detach().cpu().double(), ref["grads"][k].double()
+        n, d = float((a - r).pow(2).sum()), float(r.pow(2).sum())
+        num, den = num + n, den + d
+        if (n / (d + 1e-300)) ** 0.5 > worst[1]:
+            worst = (k, (n / (d + 1e-300)) ** 0.5)
+    e_g = (num / den) ** 0.5
+    print(f"ConvNet 128^3 vs oracle: logits {e_y:.2e} of their maximum, keypoints {e_p:.2e}, weight gradients rel-L2 {e_g:.2e} "
+          f"(worst tensor {worst[0]} {worst[1]:.2e})")
+    assert e_y <= 1e-4 and e_p <= 1e-4, (e_y, e_p)
+    assert e_g <= 2e-3 and worst[1] <= 1e-2, (e_g, worst)
+
+
 def test_convblock_group_norm():
     from keymorph_amd import backbone_ops as B
     g = gen(5)
