@@ -107,21 +107,24 @@ def test_two_rank_data_parallel_step_and_sharded_groupwise():
     np.testing.assert_allclose(got.numpy(), ref["groupgrids"].cpu().numpy(), atol=5e-3)
 
 
-def test_bench_self_launch_runs_the_hip_step_on_two_ranks():
-    """`python bench.py --gpus 2` with NO launcher (how the driver calls it): bench.py starts the two ranks itself, each runs
-    the HIP training step, the gradients go through the process group (RCCL with >= 2 devices; on a 1-GPU box the two ranks
-    share device 0 over gloo -- test hooks), and the ONE line says n_gpus = rccl_ranks = 2.  `--gpus 8` on a box with fewer
-    than 8 devices exits 2 instead of printing `n_gpus: 1` (round-3 verdict)."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_self_launch_runs_the_hip_step_on_n_ranks(world):
+    """`python bench.py --gpus N` with NO launcher (how the driver calls it): bench.py starts the N ranks itself, each runs
+    the HIP training step, the gradients go through the process group (RCCL with >= N devices; on a smaller box the ranks
+    share device 0 over gloo -- test hooks), and the ONE line says n_gpus = rccl_ranks = N.  N = 8 is BASELINE configs[3]'s
+    layout (2 pairs per rank, 16 pairs per step) and configs[4]'s (8 subjects, one per rank, one all-gather).  `--gpus 8`
+    WITHOUT the hooks on a box with fewer than 8 devices exits 2 instead of printing `n_gpus: 1` (round-3 verdict)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    shared = torch.cuda.device_count() < 2
+    shared = torch.cuda.device_count() < world
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     if shared:
         env.update(KEYMORPH_DIST_BACKEND="gloo", KEYMORPH_SHARE_GPU="1")
-    args = ["--gpus", "2", "--size", "32", "--keypoints", "16", "--steps", "2", "--warmup", "1", "--dice", "1", "--also-f32", "0",
-            "--eval-steps", "1", "--groupwise", "3", "--convnet", "0", "--sampler", "0", "--transform", "tps_1"]
+    args = ["--gpus", str(world), "--size", "32", "--keypoints", "16", "--steps", "2", "--warmup", "1", "--dice", "1",
+            "--also-f32", "0", "--eval-steps", "1", "--groupwise", "8" if world == 8 else "3", "--convnet", "0", "--sampler", "0",
+            "--transform", "tps_1"]
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -129,11 +132,11 @@ def test_bench_self_launch_runs_the_hip_step_on_two_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     cfg = d["config"]
-    assert d["n_gpus"] == 2 and cfg["rccl_ranks"] == 2 and cfg["global_pairs"] == 4
+    assert d["n_gpus"] == world and cfg["rccl_ranks"] == world and cfg["global_pairs"] == 2 * world
     assert cfg["backend"] == ("gloo" if shared else "nccl") and cfg["launcher"] == "bench.py self_launch"
     assert d["value"] > 0 and cfg["allreduce_ms_per_step"] > 0 and len(cfg["rank_ms_per_step_min_max"]) == 2
     assert "eval_pairs_per_s" in d and "groupwise_subjects_per_s" in d and "dice_pairs_per_s" in d, d.keys()
-    if torch.cuda.device_count() < 8:
+    if world == 2 and torch.cuda.device_count() < 8:
         r8 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env if not shared else
                             {k: v for k, v in env.items() if not k.startswith("KEYMORPH_")}, capture_output=True, text=True,
                             timeout=300)
