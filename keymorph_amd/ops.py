@@ -293,9 +293,9 @@ class _WarpDiceRows(torch.autograd.Function):
 
 
 def warp_dice_ok(x: Tensor, grid: Tensor) -> bool:
-    """does the fused warp + Dice pass apply?  (5-D, bilinear lane-contiguous sampler: W >= 2, < 2^31 voxels per channel
-    plane, <= 128 channels; the grid is the only input that needs a gradient)"""
-    return (x.dim() == 5 and grid.dim() == 5 and x.shape[4] >= 2 and x.shape[2] * x.shape[3] * x.shape[4] < 2 ** 31
+    """does the fused warp + Dice pass apply?  (5-D, bilinear lane-contiguous sampler with 32-bit byte offsets: W >= 2,
+    < 2^30 voxels per channel plane, <= 128 channels; the grid is the only input that needs a gradient)"""
+    return (x.dim() == 5 and grid.dim() == 5 and x.shape[4] >= 2 and x.shape[2] * x.shape[3] * x.shape[4] < 2 ** 30
             and x.shape[1] <= 128 and not x.requires_grad)
 
 
