@@ -476,6 +476,11 @@ __global__ __launch_bounds__(256) void tps_assemble_kernel(const float* __restri
   A[(size_t)b * a_stride + (size_t)i * lda + j] = v;
 }
 
+// (KMH_LU_EXP: timing experiments only, tools/build_exp_lib.sh -DKMH_LU_EXP=<bits>; results are garbage with any bit set.
+//  1 = no trailing update, 2 = no U12 strip, 4 = no pivot search, 8 = no rank-1 update inside the panel)
+#ifndef KMH_LU_EXP
+#define KMH_LU_EXP 0
+#endif
 // Blocked right-looking LU with partial pivoting, one workgroup per sample.
 // LDS: sP[m][NB+1] (panel, rows k0..n) then sU[NB][ncols] (U12 strip).
 template <int NB, bool MFMA64>
@@ -516,6 +521,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
       // pivot search over rows j..m-1 of column j
       double best = -1.0;
       int bi = j;
+      if (KMH_LU_EXP & 4) { if (tid == 0) s_piv[j] = j; __syncthreads(); } else {
       for (int r = j + tid; r < m; r += LU_TPB) {
         const double v = fabs(sP[r * PS + j]);
         if (v > best) { best = v; bi = r; }
@@ -540,6 +546,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
         if (lane == 0) { s_piv[j] = bi; if (!(best > 0.0)) bad = 1; }
       }
       __syncthreads();
+      }
       const int p = s_piv[j];
       if (p != j && tid < nb) {
         const double t = sP[j * PS + tid];
@@ -551,6 +558,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
       // scale + rank-1 update of the remaining panel columns: one thread per row (rows are
       // private to their thread; row j is read-only here), so no extra barrier is needed
       const double pinv = 1.0 / sP[j * PS + j];
+      if (!(KMH_LU_EXP & 8))
       for (int r = j + 1 + tid; r < m; r += LU_TPB) {
         const double l = sP[r * PS + j] * pinv;
         sP[r * PS + j] = l;
@@ -568,6 +576,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
     const int ncols = n - k0 - nb;
     if (ncols > 0) {
       // 5. U12 = L11^-1 A12, one thread per column
+      if (!(KMH_LU_EXP & 2))
       for (int c = tid; c < ncols; c += LU_TPB) {
         double col[NB];
 #pragma unroll
@@ -590,7 +599,8 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
       // factorisation, which the round-2 experiments went after, is the smaller part); a matrix-core tile reads 2
       // per 16.  A / B operands: lane l holds L[r0 + (l & 15)][4 s + (l >> 4)] and U[4 s + (l >> 4)][c0 + (l & 15)];
       // result register q of lane l is row (l >> 4) + 4 q, column l & 15.
-      if (MFMA64) {
+      if (KMH_LU_EXP & 1) {
+      } else if (MFMA64) {
         typedef double kmh_d4 __attribute__((ext_vector_type(4)));
         const int t16 = (ncols + 15) / 16;
         const int li = lane & 15, lk = lane >> 4;
