@@ -291,12 +291,11 @@ template <int MODE, bool FUSE_MSE, bool FUSE_GRAD = false>
 __global__ __launch_bounds__(TPB) void sample_fwd_lc_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ out,
     const float* __restrict__ fixed, double* __restrict__ partial, int C, int D, int H, int W, long long ovox,
-    float* __restrict__ dgrid = nullptr, float gcoef = 0.f /* 2 / (N C voxels) */, int xcd = 1) {
+    float* __restrict__ dgrid = nullptr, float gcoef = 0.f /* 2 / (N C voxels) */) {
   __shared__ __attribute__((aligned(16))) float sg[TPB * PASSES * 3];
   const int n = blockIdx.y, tid = threadIdx.x;
-  // xcd: chunk of this block such that every XCD (= blockIdx.x % 8) sweeps ONE contiguous range of chunks: the chunks next
-  // to each other (and one z slice apart) gather from the same cache lines, which then sit in ONE L2 instead of 8
-  const long long vb = (long long)(xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * (TPB * PASSES);
+  // (one contiguous chunk range per XCD -- xcd_remap of the block index -- measured slower: DESIGN.md section 8, round 4)
+  const long long vb = (long long)blockIdx.x * (TPB * PASSES);
   const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
   stage_rows(grid + ((long long)n * ovox + vb) * 3, cnt, sg, tid);
   __syncthreads();
@@ -389,11 +388,11 @@ __global__ __launch_bounds__(TPB) void sample_fwd_lc_kernel(
 
 __global__ __launch_bounds__(TPB) void sample_bwd_grid_lc_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ gout,
-    float* __restrict__ dgrid, int C, int D, int H, int W, long long ovox, int xcd = 1) {
+    float* __restrict__ dgrid, int C, int D, int H, int W, long long ovox) {
   __shared__ __attribute__((aligned(16))) float sg[TPB * PASSES * 3];
   constexpr int ILP = 2;                   // voxels whose 4 pair-gathers are in flight together (ILP = 1: 151 us, 2: 138 us)
   const int n = blockIdx.y, tid = threadIdx.x;
-  const long long vb = (long long)(xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * (TPB * PASSES);
+  const long long vb = (long long)blockIdx.x * (TPB * PASSES);
   const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
   stage_rows(grid + ((long long)n * ovox + vb) * 3, cnt, sg, tid);
   __syncthreads();
@@ -538,12 +537,12 @@ __device__ __forceinline__ float blend8f(const float v[8], float fx, float fy, f
   return blend8(v, t);
 }
 
-// XCD-aware walk over a sample's chunks for a PERSISTENT launch (gridDim.x a multiple of 8, ideally no more blocks than
-// are resident at once).  A rotated / sheared sampling grid makes a 4-row chunk touch ~50 source rows, and the chunks next
-// to it (and the next z slice) touch the same cache lines; dealt round-robin, neighbouring chunks land on 8 different XCDs
-// and every one of their L2s fetches its own copy (measured on the strided version: 3.4x the algorithmic bytes through
-// FETCH_SIZE, L2 hit rate 37 %).  Here XCD k (= blockIdx.x % 8: observed dispatch order, used for speed only -- any
-// placement is correct) owns ONE contiguous range of chunks and its resident blocks sweep it side by side.
+// Walk over a sample's chunks for a PERSISTENT launch (gridDim.x a multiple of 8): XCD k (= blockIdx.x % 8: observed
+// dispatch order, used for locality only -- any placement is correct) owns ONE contiguous range of chunks and its resident
+// blocks sweep it side by side, so that chunks next to each other (a rotated grid makes a 4-row chunk touch ~50 source rows
+// that its neighbours touch too) meet in one L2.  Measured: the same speed and the same FETCH_SIZE as the plain strided
+// walk at 2 x 14 x 256^3 (the duplicate fetches are not cross-XCD duplicates: DESIGN.md section 8); kept because it is no
+// slower and the kernels need a chunk loop for the prefetch of the next chunk's grid rows anyway.
 struct ChunkWalk { int cur, end, step; };
 __device__ __forceinline__ ChunkWalk chunk_walk(int b, int nb, int nchunk) {
   const int NX = nb < 8 ? nb : 8;            // fewer than 8 blocks: as many ranges as blocks (every range needs an owner)
@@ -579,7 +578,7 @@ __device__ __forceinline__ void gather_labels(__amdgpu_buffer_rsrc_t r, const Ta
 }
 
 // partial: (N, gridDim.x, C, 3) doubles
-template <int WD_ILP, int UC = 1, bool LAB = false>
+template <int WD_ILP, bool LAB = false>
 __global__ __launch_bounds__(TPB) void warp_dice_sums_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ fixed,
     double* __restrict__ partial, int C, int D, int H, int W, long long ovox, int nchunk,
@@ -647,7 +646,7 @@ __global__ __launch_bounds__(TPB) void warp_dice_sums_kernel(
           lab[u].t = live ? t : 255u;
         }
       }
-#pragma unroll UC
+#pragma unroll 1
       for (int c = 0; c < C; ++c) {
         float v[WD_ILP][8], tv[WD_ILP];
         if constexpr (LAB) {
@@ -701,7 +700,7 @@ __global__ __launch_bounds__(TPB) void warp_dice_final_kernel(const double* __re
   if (lane == 0) sums[e] = (float)s;
 }
 
-template <int WD_ILP, int UC = 1, bool LAB = false>
+template <int WD_ILP, bool LAB = false>
 __global__ __launch_bounds__(TPB) void warp_dice_grad_kernel(
     const float* __restrict__ x, const float* __restrict__ grid, const float* __restrict__ fixed,
     const float* __restrict__ ca, const float* __restrict__ cb, float* __restrict__ dgrid, int C, int D, int H, int W,
@@ -769,7 +768,7 @@ __global__ __launch_bounds__(TPB) void warp_dice_grad_kernel(
           lab[u].t = live ? t : 255u;
         }
       }
-#pragma unroll UC
+#pragma unroll 1
       for (int c = 0; c < C; ++c) {
         const float a = ca[n * C + c], b = cb[n * C + c];
         float v[WD_ILP][8], tv[WD_ILP];
@@ -1054,12 +1053,6 @@ __global__ __launch_bounds__(TPB) void jacdet_final_kernel(const double* __restr
   }
 }
 
-static int sampler_xcd() {      // A/B switch, OFF by default: one contiguous chunk range per XCD measured 102.6 us vs 88.7 us
-                                // (C = 1, 256^3) and flat for C = 14 -- the L2s' duplicate fetches are served by the
-                                // Infinity Cache, and contiguous ranges concentrate each XCD on fewer HBM channels
-  static const int v = getenv("KMH_SAMPLER_XCD") ? atoi(getenv("KMH_SAMPLER_XCD")) : 0;
-  return v;
-}
 static bool lane_contiguous_ok(int D, int H, int W) {
   static const bool force_old = getenv("KMH_SAMPLER_OLD") != nullptr;   // A/B switch for tools/bench_sampler.py
   return !force_old && W >= 2 && (long long)D * H * W < (1ll << 31);
@@ -1077,9 +1070,9 @@ KMH_API int kmh_grid_sample3d_fwd(const float* x, const float* grid, float* out,
   hipStream_t s = (hipStream_t)stream;
   if (lane_contiguous_ok(D, H, W)) {
     if (mode == 0)
-      sample_fwd_lc_kernel<0, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox, nullptr, 0.f, sampler_xcd());
+      sample_fwd_lc_kernel<0, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox);
     else
-      sample_fwd_lc_kernel<1, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox, nullptr, 0.f, sampler_xcd());
+      sample_fwd_lc_kernel<1, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox);
   } else if (mode == 0) {
     sample_fwd_kernel<0, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox);
   } else {
@@ -1096,7 +1089,7 @@ KMH_API int kmh_warp_mse_fwd(const float* x, const float* grid, const float* fix
   if ((long long)g.x * g.y > 65536 * 3) return -22;
   hipStream_t s = (hipStream_t)stream;
   if (lane_contiguous_ok(D, H, W)) {
-    sample_fwd_lc_kernel<0, true><<<g, TPB, 0, s>>>(x, grid, out, fixed, (double*)ws, C, D, H, W, ovox, nullptr, 0.f, sampler_xcd());
+    sample_fwd_lc_kernel<0, true><<<g, TPB, 0, s>>>(x, grid, out, fixed, (double*)ws, C, D, H, W, ovox);
   } else {
     sample_fwd_kernel<0, true><<<g, TPB, 0, s>>>(x, grid, out, fixed, (double*)ws, C, D, H, W, ovox);
   }
@@ -1132,7 +1125,7 @@ KMH_API int kmh_warp_mse_fwd_grad(const float* x, const float* grid, const float
   hipStream_t s = (hipStream_t)stream;
   const double cnt = (double)N * C * (double)ovox;
   sample_fwd_lc_kernel<0, true, true><<<g, TPB, 0, s>>>(x, grid, out, fixed, (double*)ws, C, D, H, W, ovox, dgrid,
-                                                        (float)(2.0 / cnt), sampler_xcd());
+                                                        (float)(2.0 / cnt));
   finalize_mean_kernel<<<1, TPB, 0, s>>>((const double*)ws, (int)(g.x * g.y), 1.0 / cnt, out_loss);
   return KMH_LAUNCH_CHECK();
 }
@@ -1152,7 +1145,7 @@ KMH_API int kmh_grid_sample3d_bwd_grid(const float* x, const float* grid, const 
   const long long ovox = (long long)Do * Ho * Wo;
   dim3 g(ceil_div(ovox, (long long)TPB * VPT), N);
   if (lane_contiguous_ok(D, H, W))
-    sample_bwd_grid_lc_kernel<<<g, TPB, 0, (hipStream_t)stream>>>(x, grid, gout, dgrid, C, D, H, W, ovox, sampler_xcd());
+    sample_bwd_grid_lc_kernel<<<g, TPB, 0, (hipStream_t)stream>>>(x, grid, gout, dgrid, C, D, H, W, ovox);
   else
     sample_bwd_grid_kernel<<<g, TPB, 0, (hipStream_t)stream>>>(x, grid, gout, dgrid, C, D, H, W, ovox);
   return KMH_LAUNCH_CHECK();
@@ -1222,13 +1215,13 @@ KMH_API int kmh_warp_dice_sums(const float* x, const float* grid, const float* f
   const dim3 g((unsigned)nb, N);
   // with label maps: BOTH variants are launched with the same grid; the device flag lets exactly one of them work
   if (labs)
-    warp_dice_sums_kernel<4, 1, true><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk, lab_x,
+    warp_dice_sums_kernel<4, true><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk, lab_x,
                                                          lab_fixed, gate);
   if (ilp == 4)
-    warp_dice_sums_kernel<4, 1><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk, nullptr, nullptr,
+    warp_dice_sums_kernel<4><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk, nullptr, nullptr,
                                                   labs ? gate : nullptr);
   else
-    warp_dice_sums_kernel<2, 1><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk, nullptr, nullptr,
+    warp_dice_sums_kernel<2><<<g, TPB, 0, s>>>(x, grid, fixed, (double*)ws, C, D, H, W, ovox, nchunk, nullptr, nullptr,
                                                   labs ? gate : nullptr);
   const int total = N * C * 3;
   warp_dice_final_kernel<<<ceil_div(total, TPB / kWave), TPB, 0, s>>>((const double*)ws, (int)nb, C, total, sums);
@@ -1268,13 +1261,13 @@ KMH_API int kmh_warp_dice_bwd_grid(const float* x, const float* grid, const floa
   const dim3 g(nb, N);
   hipStream_t s = (hipStream_t)stream;
   if (labs)
-    warp_dice_grad_kernel<2, 1, true><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk, lab_x,
+    warp_dice_grad_kernel<2, true><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk, lab_x,
                                                          lab_fixed, gate);
   if (ilp == 4)
-    warp_dice_grad_kernel<4, 1><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk, nullptr, nullptr,
+    warp_dice_grad_kernel<4><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk, nullptr, nullptr,
                                                   labs ? gate : nullptr);
   else
-    warp_dice_grad_kernel<2, 1><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk, nullptr, nullptr,
+    warp_dice_grad_kernel<2><<<g, TPB, 0, s>>>(x, grid, fixed, ca, cb, dgrid, C, D, H, W, ovox, nchunk, nullptr, nullptr,
                                                   labs ? gate : nullptr);
   return KMH_LAUNCH_CHECK();
 }
