@@ -481,6 +481,9 @@ __global__ __launch_bounds__(256) void tps_assemble_kernel(const float* __restri
 #ifndef KMH_LU_EXP
 #define KMH_LU_EXP 0
 #endif
+#ifndef KMH_LU_KEYED
+#define KMH_LU_KEYED 1          // 0: round 3's four-barrier column step (A/B: tools/build_exp_lib.sh -DKMH_LU_KEYED=0)
+#endif
 // Blocked right-looking LU with partial pivoting, one workgroup per sample.
 // LDS: sP[m][NB+1] (panel, rows k0..n) then sU[NB][ncols] (U12 strip).
 template <int NB, bool MFMA64>
@@ -494,6 +497,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
   __shared__ double s_val[LU_TPB / kWave];
   __shared__ int s_idx[LU_TPB / kWave];
   __shared__ int s_piv[NB];
+  __shared__ unsigned long long s_key[NB];      // KMH_LU_KEYED: (magnitude, row) key of every panel column's pivot
   // Row interchanges are NOT carried out in memory: rowmap[i] = the physical (= original) row that currently sits at
   // position i of the pivoted order.  Every access to a row of A goes through it, a pivot swaps two of its entries, and the
   // solve reads the same map (ipiv_all receives rowmap, not LAPACK's sequential interchanges).  Swapping the rows of the
@@ -517,6 +521,58 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
     }
     __syncthreads();
     // 2. unblocked LU of the panel
+    if constexpr (KMH_LU_KEYED) {
+      // Round 4: two barriers per column instead of four.  The pivot of column j+1 is found WHILE column j's rank-1 update
+      // writes it: every thread turns |its new entry| into a 64-bit key (magnitude bits with the low 11 replaced by
+      // 2047 - row, so that equal magnitudes resolve to the smallest row like LAPACK's idamax and a plain unsigned maximum is
+      // order independent), a wave reduces with shuffles and ONE LDS atomicMax per wave publishes it -- no second reduction
+      // stage on wave 0, no separate search phase re-reading the column.  (Magnitudes are compared to 42 mantissa bits: a
+      // pivot within 2^-42 of the largest is as good as the largest.)
+      auto row_key = [](double v, int r) -> unsigned long long {
+        const double a = fabs(v);
+        const unsigned long long b = (a == a) ? (unsigned long long)__double_as_longlong(a) : 0ull;     // NaN never wins
+        return (b & ~0x7FFull) | (unsigned long long)(0x7FF - r);
+      };
+      auto publish = [&](unsigned long long key, int col) {
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+          const unsigned long long ok = __shfl_xor(key, o, kWave);
+          key = ok > key ? ok : key;
+        }
+        if (lane == 0 && key) atomicMax(&s_key[col], key);
+      };
+      if (tid < NB) s_key[tid] = 0ull;
+      __syncthreads();
+      {
+        unsigned long long key = 0ull;
+        for (int r = tid; r < m; r += LU_TPB) { const unsigned long long k = row_key(sP[r * PS], r); key = k > key ? k : key; }
+        publish(key, 0);
+      }
+      for (int j = 0; j < nb; ++j) {
+        __syncthreads();               // column j's keys are in (and the previous column's update is visible)
+        const unsigned long long kj = s_key[j];
+        const int p = 0x7FF - (int)(kj & 0x7FFull);
+        if (tid == 0 && (kj >> 11) == 0ull) bad = 1;       // the whole column is zero (or NaN): singular
+        const bool have = (kj >> 11) != 0ull;
+        if (have && p != j && tid < nb) {
+          const double t = sP[j * PS + tid];
+          sP[j * PS + tid] = sP[p * PS + tid];
+          sP[p * PS + tid] = t;
+        }
+        if (have && p != j && tid == LU_TPB - 1) { const int t = rowmap[k0 + j]; rowmap[k0 + j] = rowmap[k0 + p]; rowmap[k0 + p] = t; }
+        __syncthreads();
+        const double pinv = 1.0 / sP[j * PS + j];
+        unsigned long long key = 0ull;
+        for (int r = j + 1 + tid; r < m; r += LU_TPB) {
+          const double l = sP[r * PS + j] * pinv;
+          sP[r * PS + j] = l;
+          for (int c = j + 1; c < nb; ++c) sP[r * PS + c] -= l * sP[j * PS + c];
+          if (j + 1 < nb) { const unsigned long long k = row_key(sP[r * PS + j + 1], r); key = k > key ? k : key; }
+        }
+        if (j + 1 < nb) publish(key, j + 1);
+      }
+      __syncthreads();
+    } else {
     for (int j = 0; j < nb; ++j) {
       // pivot search over rows j..m-1 of column j
       double best = -1.0;
@@ -565,6 +621,7 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
         for (int c = j + 1; c < nb; ++c) sP[r * PS + c] -= l * sP[j * PS + c];
       }
       __syncthreads();
+    }
     }
     // 3. (no interchanges in memory: rowmap)
     // 4. panel back to global
