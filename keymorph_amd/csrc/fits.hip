@@ -733,6 +733,225 @@ __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aal
   if (tid == 0) info_all[blockIdx.x] = bad;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Cluster variant (round 4): G workgroups per system.  The phase breakdown of the one-workgroup kernel
+// put 45 % of a fit into the U12 strip + trailing update, which are not arithmetic but ONE CU's path to L2 (every panel reads
+// and writes the whole trailing matrix).  Here workgroup 0 of a system factorises each panel exactly as above and publishes
+// it (+ its pivots); all G workgroups then take a contiguous slice of the trailing COLUMNS each -- U12 strip and A22 update of
+// a column slice need nothing from another slice -- and report back.  Two hand-offs per panel through two monotone counters
+// in global memory: `ready` (panels published, written by workgroup 0) and `done` (slice updates finished, incremented by
+// every workgroup), agent-scope release / acquire (the workgroups may sit on different XCDs whose L2s are not coherent).
+// Every wait is bounded (a workgroup that gives up raises `abort_flag`, which ends every other wait too, and the fit
+// reports info = 2): the launcher only uses this kernel when all N * G workgroups are resident at once.
+constexpr int CL_SPIN_LIMIT = 1 << 20;      // x ~1 us per probe: about a second, then give up
+
+__device__ __forceinline__ bool cl_wait_ge(int* counter, int value, int* abort_flag) {
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    int it = 0, ok = 1;
+    // probe with RELAXED loads (an acquire per probe invalidates this CU's caches every time), ONE acquire fence at the end
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
+      if (++it > CL_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!ok) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ok = ok;
+  }
+  __syncthreads();                       // the acquiring lane's invalidate covers this CU's L1: the others read after the barrier
+  const bool ok = s_ok != 0;
+  __syncthreads();                       // (s_ok may be rewritten by the next wait)
+  return ok;
+}
+// Every thread's global stores of this phase -> visible to the other workgroups, then the counter moves.  The barrier orders all
+// waves' stores before lane 0 (they have left for L2 when a wave passes it), and lane 0's agent-scope RELEASE is cumulative over
+// that: its L2 write-back covers the whole workgroup's lines.  (A __threadfence() in every thread as well -- 16 waves each
+// writing the L2 back -- cost 0.42 ms per fit and changed nothing.)
+__device__ __forceinline__ void cl_publish(int* counter, bool add, int value) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (add) __hip_atomic_fetch_add(counter, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(counter, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(LU_TPB) void tps_lu_cluster_kernel(double* __restrict__ Aall, int* __restrict__ ipiv_all,
+                                                                int* __restrict__ info_all, int n, int lda, size_t a_stride,
+                                                                int* __restrict__ pivs_all /* (N, n) */,
+                                                                int* __restrict__ sync_all /* (N, 4): ready, done, abort */) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int PS = NB + 1;
+  double* sP = smem;                       // [n][PS]
+  double* sU = smem + (size_t)n * PS;      // [NB][n]
+  int* rowmap = reinterpret_cast<int*>(smem + (size_t)n * PS + (size_t)NB * n);     // [n]
+  __shared__ unsigned long long s_key[NB];
+  __shared__ int s_pv[NB];
+  const int G = gridDim.x, g = blockIdx.x, b = blockIdx.y;
+  double* A = Aall + (size_t)b * a_stride;
+  int* pivs = pivs_all + (size_t)b * n;
+  int* ready = sync_all + 4 * b;
+  int* done = ready + 1;
+  int* abort_flag = ready + 2;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1), wid = tid / kWave;
+  int bad = 0;
+  for (int e = tid; e < n; e += LU_TPB) rowmap[e] = e;
+  __syncthreads();
+  auto row_key = [](double v, int r) -> unsigned long long {
+    const double a = fabs(v);
+    const unsigned long long bits = (a == a) ? (unsigned long long)__double_as_longlong(a) : 0ull;
+    return (bits & ~0x7FFull) | (unsigned long long)(0x7FF - r);
+  };
+  auto publish_key = [&](unsigned long long key, int col) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+      const unsigned long long ok = __shfl_xor(key, o, kWave);
+      key = ok > key ? ok : key;
+    }
+    if (lane == 0 && key) atomicMax(&s_key[col], key);
+  };
+
+  int panel = 0;
+  for (int k0 = 0; k0 < n; k0 += NB, ++panel) {
+    const int nb = (n - k0 < NB) ? (n - k0) : NB;
+    const int m = n - k0;
+    const int ncols = n - k0 - nb;
+    if (g == 0) {
+      // every slice update with the previous panel has been reported (and is visible after the acquire)
+      if (!cl_wait_ge(done, panel * G, abort_flag)) { bad = 2; break; }
+      for (int e = tid; e < m * nb; e += LU_TPB) {
+        const int r = e / nb, c = e % nb;
+        sP[r * PS + c] = A[(size_t)rowmap[k0 + r] * lda + k0 + c];
+      }
+      if (tid < NB) s_key[tid] = 0ull;
+      __syncthreads();
+      {
+        unsigned long long key = 0ull;
+        for (int r = tid; r < m; r += LU_TPB) { const unsigned long long k = row_key(sP[r * PS], r); key = k > key ? k : key; }
+        publish_key(key, 0);
+      }
+      for (int j = 0; j < nb; ++j) {
+        __syncthreads();
+        const unsigned long long kj = s_key[j];
+        const bool have = (kj >> 11) != 0ull;
+        const int p = have ? 0x7FF - (int)(kj & 0x7FFull) : j;
+        if (tid == 0) { if (!have) bad = 1; pivs[k0 + j] = p; }
+        if (p != j && tid < nb) {
+          const double t = sP[j * PS + tid];
+          sP[j * PS + tid] = sP[p * PS + tid];
+          sP[p * PS + tid] = t;
+        }
+        if (p != j && tid == LU_TPB - 1) { const int t = rowmap[k0 + j]; rowmap[k0 + j] = rowmap[k0 + p]; rowmap[k0 + p] = t; }
+        __syncthreads();
+        const double pinv = 1.0 / sP[j * PS + j];
+        unsigned long long key = 0ull;
+        for (int r = j + 1 + tid; r < m; r += LU_TPB) {
+          const double l = sP[r * PS + j] * pinv;
+          sP[r * PS + j] = l;
+          for (int c = j + 1; c < nb; ++c) sP[r * PS + c] -= l * sP[j * PS + c];
+          if (j + 1 < nb) { const unsigned long long k = row_key(sP[r * PS + j + 1], r); key = k > key ? k : key; }
+        }
+        if (j + 1 < nb) publish_key(key, j + 1);
+      }
+      __syncthreads();
+      for (int e = tid; e < m * nb; e += LU_TPB) {
+        const int r = e / nb, c = e % nb;
+        A[(size_t)rowmap[k0 + r] * lda + k0 + c] = sP[r * PS + c];
+      }
+      cl_publish(ready, false, panel + 1);
+    } else {
+      if (!cl_wait_ge(ready, panel + 1, abort_flag)) { bad = 2; break; }
+      // this workgroup's copy of the row map follows the published pivots; then the factorised panel comes in
+      if (tid < nb) s_pv[tid] = pivs[k0 + tid];
+      __syncthreads();
+      if (tid == 0)
+        for (int j = 0; j < nb; ++j) {
+          const int p = s_pv[j];
+          if (p != j) { const int t = rowmap[k0 + j]; rowmap[k0 + j] = rowmap[k0 + p]; rowmap[k0 + p] = t; }
+        }
+      __syncthreads();
+      if (ncols > 0)
+        for (int e = tid; e < m * nb; e += LU_TPB) {
+          const int r = e / nb, c = e % nb;
+          sP[r * PS + c] = A[(size_t)rowmap[k0 + r] * lda + k0 + c];
+        }
+    }
+    __syncthreads();
+    if (ncols <= 0) continue;            // the last panel has nothing behind it
+    // ---- this workgroup's slice of the trailing columns: whole 16-column tiles, dealt contiguously
+    const int t16 = (ncols + 15) / 16;
+    const int per = (t16 + G - 1) / G;
+    const int ct0 = g * per, ct1 = (ct0 + per < t16) ? ct0 + per : t16;       // column tiles [ct0, ct1)
+    const int c_lo = ct0 * 16, c_hi = (ct1 * 16 < ncols) ? ct1 * 16 : ncols;
+    if (ct0 < ct1) {
+      // U12 = L11^-1 A12 for the slice, one thread per column
+      for (int c = c_lo + tid; c < c_hi; c += LU_TPB) {
+        double col[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) col[r] = (r < nb) ? A[(size_t)rowmap[k0 + r] * lda + k0 + nb + c] : 0.0;
+#pragma unroll
+        for (int r = 1; r < NB; ++r) {
+          double a = col[r];
+#pragma unroll
+          for (int k = 0; k < r; ++k) a -= sP[r * PS + k] * col[k];
+          col[r] = a;
+        }
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+          if (r < nb) { sU[r * n + c] = col[r]; A[(size_t)rowmap[k0 + r] * lda + k0 + nb + c] = col[r]; }
+      }
+      __syncthreads();
+      // A22[:, slice] -= L21 U12[:, slice] on the fp64 matrix cores (as tps_lu_kernel)
+      typedef double kmh_d4 __attribute__((ext_vector_type(4)));
+      const int li = lane & 15, lk = lane >> 4;
+      constexpr int TU = 4;
+      constexpr int NWV = LU_TPB / kWave;
+      const int nct = ct1 - ct0, ntile = t16 * nct;
+      for (int tile0 = wid; tile0 < ntile; tile0 += NWV * TU) {
+        double oldv[TU][4];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          const int tile = tile0 + u * NWV;
+          const int r0 = (tile / nct) * 16, c0 = (ct0 + tile % nct) * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = r0 + lk + 4 * q, c = c0 + li;
+            oldv[u][q] = (tile < ntile && r < ncols && c < ncols) ? A[(size_t)rowmap[k0 + nb + r] * lda + k0 + nb + c] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          const int tile = tile0 + u * NWV;
+          if (tile >= ntile) break;                          // wave-uniform
+          const int r0 = (tile / nct) * 16, c0 = (ct0 + tile % nct) * 16;
+          kmh_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s4 = 0; s4 < NB / 4; ++s4) {
+            const int k = 4 * s4 + lk;
+            const double a = (r0 + li < ncols && k < nb) ? sP[(nb + r0 + li) * PS + k] : 0.0;
+            const double bb = (c0 + li < ncols && k < nb) ? sU[k * n + c0 + li] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = r0 + lk + 4 * q, c = c0 + li;
+            if (r < ncols && c < ncols) A[(size_t)rowmap[k0 + nb + r] * lda + k0 + nb + c] = oldv[u][q] - acc[q];
+          }
+        }
+      }
+    }
+    cl_publish(done, true, 1);
+  }
+  if (g == 0) {
+    int* ipiv = ipiv_all + (size_t)b * n;
+    for (int e = tid; e < n; e += LU_TPB) ipiv[e] = rowmap[e];
+    if (tid == 0) info_all[b] = bad;
+  } else if (bad && tid == 0) {
+    atomicMax(&info_all[b], bad);        // (a worker that gave up: make sure the fit reports it)
+  }
+}
+
 // Solve (P A = L U) x = b for 3 right-hand sides.  b/x (n x 3) doubles in LDS.  One workgroup
 // per sample; blocked substitution: each 16x16 diagonal block is staged in LDS and solved by
 // three lanes (one per right-hand side), the off-diagonal strip is applied by all threads
@@ -953,7 +1172,7 @@ static inline int lda_of(int n) { return (n + 7) & ~7; }
 static inline size_t solve_lds(int n) { return (size_t)n * 3 * sizeof(double) + (size_t)n * sizeof(int); }
 
 struct FitWs {
-  double* A; int* ipiv; int* info; double* g64; size_t a_stride; int lda;
+  double* A; int* ipiv; int* info; double* g64; size_t a_stride; int lda; int* pivs; int* sync;
 };
 static FitWs carve(void* ws, int N, int T) {
   FitWs f;
@@ -964,7 +1183,9 @@ static FitWs carve(void* ws, int N, int T) {
   f.A = (double*)p; p += (size_t)N * f.a_stride * sizeof(double);
   f.g64 = (double*)p; p += (size_t)N * n * 3 * sizeof(double);
   f.ipiv = (int*)p; p += (size_t)N * n * sizeof(int);
-  f.info = (int*)p;
+  f.info = (int*)p; p += (((size_t)N * sizeof(int)) + 15) & ~(size_t)15;
+  f.pivs = (int*)p; p += (size_t)N * n * sizeof(int);
+  f.sync = (int*)p;             // N x 4 ints: ready, done, abort, -
   return f;
 }
 
@@ -1006,7 +1227,7 @@ KMH_API int kmh_affine_inverse_bwd(const float* dMinv, const float* Minv, float*
 KMH_API size_t kmh_tps_fit_ws_bytes(int N, int T) {
   const int n = T + 4;
   return (size_t)N * n * lda_of(n) * sizeof(double) + (size_t)N * n * 3 * sizeof(double) +
-         (size_t)N * n * sizeof(int) + (size_t)N * sizeof(int) + 256;
+         (size_t)N * n * sizeof(int) * 2 + (size_t)N * sizeof(int) * 5 + 512;
 }
 
 template <int NB>
@@ -1019,6 +1240,20 @@ static int launch_lu(const FitWs& f, int N, int n, hipStream_t s) {
                                        (int)lds);
     if (e != hipSuccess) return (int)e;
     tps_lu_kernel<NB, false><<<N, LU_TPB, lds, s>>>(f.A, f.ipiv, f.info, n, f.lda, f.a_stride);
+    return KMH_LAUNCH_CHECK();
+  }
+  // cluster of G workgroups per system when the systems are large enough to pay for the hand-offs and every workgroup of the
+  // launch is resident at once (one per CU: 136 KB of LDS): KEYMORPH_TPS_LU_CLUSTER=<G> (0 / 1 = one workgroup per system)
+  static const int genv = getenv("KEYMORPH_TPS_LU_CLUSTER") ? atoi(getenv("KEYMORPH_TPS_LU_CLUSTER")) : 8;
+  int G = genv;
+  while (G > 1 && (long long)N * G > 128) G >>= 1;
+  if (G > 1 && n >= 128) {
+    hipError_t e = hipFuncSetAttribute((const void*)tps_lu_cluster_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(f.sync, 0, (size_t)N * 4 * sizeof(int), s);
+    if (e != hipSuccess) return (int)e;
+    tps_lu_cluster_kernel<NB><<<dim3(G, N), LU_TPB, lds, s>>>(f.A, f.ipiv, f.info, n, f.lda, f.a_stride, f.pivs, f.sync);
     return KMH_LAUNCH_CHECK();
   }
   hipError_t e = hipFuncSetAttribute((const void*)tps_lu_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
