@@ -962,7 +962,8 @@ __global__ __launch_bounds__(LU_TPB) void tps_solve_kernel(const double* __restr
                                                            const float* __restrict__ rhs /* (N, rows, 3) */,
                                                            int rhs_rows, float* __restrict__ out /* (N,n,3) | null */,
                                                            double* __restrict__ out64 /* (N,n,3) | null */,
-                                                           int n, int lda, size_t a_stride) {
+                                                           int n, int lda, size_t a_stride,
+                                                           const int* __restrict__ info_all = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double sb[];  // [n][3] then int piv[n]
   __shared__ double sD[SB][SB + 1];
   int* spiv = reinterpret_cast<int*>(sb + (size_t)n * 3);
@@ -1043,9 +1044,13 @@ __global__ __launch_bounds__(LU_TPB) void tps_solve_kernel(const double* __restr
     }
     __syncthreads();
   }
+  // info == 2: the factorisation gave up waiting for a workgroup of its cluster (tps_lu_cluster_kernel: its workgroups were not
+  // all resident).  That must not pass as a result: the coefficients become NaN, which every caller's finiteness check sees.
+  const bool poisoned = info_all && info_all[blockIdx.x] == 2;
   for (int e = tid; e < n * 3; e += LU_TPB) {
-    if (out) out[(size_t)blockIdx.x * n * 3 + e] = (float)sb[e];
-    if (out64) out64[(size_t)blockIdx.x * n * 3 + e] = sb[e];
+    const double v = poisoned ? __longlong_as_double(0x7ff8000000000000ll) : sb[e];
+    if (out) out[(size_t)blockIdx.x * n * 3 + e] = (float)v;
+    if (out64) out64[(size_t)blockIdx.x * n * 3 + e] = v;
   }
 }
 
@@ -1275,7 +1280,7 @@ KMH_API int kmh_tps_fit_fwd(const float* ctrl, const float* tgt, const float* lm
   else if (n <= 1150) rc = launch_lu<8>(f, N, n, s);
   else return -22;
   if (rc) return rc;
-  tps_solve_kernel<<<N, LU_TPB, solve_lds(n), s>>>(f.A, f.ipiv, tgt, T, theta, nullptr, n, f.lda, f.a_stride);
+  tps_solve_kernel<<<N, LU_TPB, solve_lds(n), s>>>(f.A, f.ipiv, tgt, T, theta, nullptr, n, f.lda, f.a_stride, f.info);
   return KMH_LAUNCH_CHECK();
 }
 
