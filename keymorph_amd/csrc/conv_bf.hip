@@ -1284,12 +1284,16 @@ __global__ __launch_bounds__(256, 3) void up2_wgrad_gemm_kernel(const float* __r
                                                                 int ntn, int ntm, const float* __restrict__ ascale,
                                                                 const float* __restrict__ bscale,
                                                                 const float* __restrict__ a_scale /* (N, Cl) | NULL */,
-                                                                const float* __restrict__ a_shift) {
+                                                                const float* __restrict__ a_shift, int xcd) {
   __shared__ __attribute__((aligned(16))) unsigned char sA[TERMS][128 * GPITCH];
   __shared__ __attribute__((aligned(16))) unsigned char sB[TERMS][128 * GPITCH];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int n = blockIdx.z;
-  int item = blockIdx.x;
+  // The column tiles of one (row tile, K slab) read the SAME rows of A.  Dealt round-robin over the XCDs, every XCD's L2 fetched
+  // them for itself: 14.75 GB per launch for 7.25 GB of G at 64^3 x 128 x 1728 (PMC), and the launch ran at the HBM rate of THAT.
+  // With one contiguous item range per XCD (xcd_remap) the tiles of a slab sit on one XCD and walk the slab together: A comes
+  // from HBM once.  (KEYMORPH_UP2_GEMM_NO_XCD=1: the round-robin order, for A/B runs.)
+  int item = xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int tn = item % ntn; item /= ntn;
   const int tm = item % ntm;
   const int slab = item / ntm;
@@ -1309,13 +1313,14 @@ __global__ __launch_bounds__(256, 3) void up2_wgrad_gemm_kernel(const float* __r
   const int k_beg = slab * kslab;
   int k_end = k_beg + kslab;
   if (k_end > V) k_end = V;
-  // staging items: (voxel pair kp, column quad cq) -> 2 float4 loads, 4 packed words per term
+  // staging items: (voxel pair kp, column quad cq) -> 2 float4 loads, 4 packed words per term.  Eight consecutive lanes take the
+  // eight quads of ONE 128-byte line of a voxel row (round 4; four lanes / 64-byte pieces before: 2.9 TB/s -> see DESIGN.md)
   constexpr int NKP = GK / 2, NIT = GK / 16;   // voxel pairs per step, staging items per thread
   float4 pa[NIT][2], pb[NIT][2];
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int e = tid + i * 256, cq = (e & 3) + 4 * (e / (4 * NKP)), kp = (e >> 2) & (NKP - 1);   // lanes: 4 quads x 16 voxel pairs
+      const int e = tid + i * 256, cq = (e & 7) + 8 * (e / (8 * NKP)), kp = (e >> 3) & (NKP - 1);   // lanes: 8 quads (one line) x 8 voxel pairs
       const int k = k0 + 2 * kp;
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       const int ca = m0 + 4 * cq, cb = n0 + 4 * cq;
@@ -1330,7 +1335,7 @@ __global__ __launch_bounds__(256, 3) void up2_wgrad_gemm_kernel(const float* __r
   float4 csc[NIT], csh[NIT];
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
-    const int e = tid + i * 256, cq = (e & 3) + 4 * (e / (4 * NKP)), ca = m0 + 4 * cq;
+    const int e = tid + i * 256, cq = (e & 7) + 8 * (e / (8 * NKP)), ca = m0 + 4 * cq;
     csc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
     csh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a_scale && ca < Cl) {
@@ -1341,7 +1346,7 @@ __global__ __launch_bounds__(256, 3) void up2_wgrad_gemm_kernel(const float* __r
   auto commit = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int e = tid + i * 256, cq = (e & 3) + 4 * (e / (4 * NKP)), kp = (e >> 2) & (NKP - 1);   // (2-way LDS write conflicts at most)
+      const int e = tid + i * 256, cq = (e & 7) + 8 * (e / (8 * NKP)), kp = (e >> 3) & (NKP - 1);   // (2-way LDS write conflicts at most)
       const bool v0 = k0 + 2 * kp < k_end, v1 = k0 + 2 * kp + 1 < k_end;     // rows past the slab stay zero (no shift)
       const float a0[4] = {v0 ? fmaf(pa[i][0].x, csc[i].x, csh[i].x) : 0.f, v0 ? fmaf(pa[i][0].y, csc[i].y, csh[i].y) : 0.f,
                            v0 ? fmaf(pa[i][0].z, csc[i].z, csh[i].z) : 0.f, v0 ? fmaf(pa[i][0].w, csc[i].w, csh[i].w) : 0.f};
@@ -1447,10 +1452,11 @@ KMH_API int kmh_up2_wgrad_gemm(const float* A, const float* B, float* C, int N, 
   const int ntn = ceil_div(J, 128), ntm = ceil_div(Cl, 128);
   hipStream_t s = (hipStream_t)stream;
   dim3 g(ntn * ntm * ns, 1, N);
+  static const int xcd = getenv("KEYMORPH_UP2_GEMM_NO_XCD") ? 0 : 1;
   if (terms == 2)
-    up2_wgrad_gemm_kernel<2><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale, a_scale, a_shift);
+    up2_wgrad_gemm_kernel<2><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale, a_scale, a_shift, xcd);
   else
-    up2_wgrad_gemm_kernel<3><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale, a_scale, a_shift);
+    up2_wgrad_gemm_kernel<3><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale, a_scale, a_shift, xcd);
   const long long per = (long long)Cl * J;
   int nb = ceil_div(per, 256);
   if (nb > 1024) nb = 1024;
