@@ -226,10 +226,12 @@ int kmh_conv3d_up2_dgrad_pack_weight(const float* w, void* packed, int Cout, int
 size_t kmh_conv3d_up2_dgrad_stats_ws_bytes(int N, int Dl, int Hl, int Wl, int Cl);
 int kmh_conv3d_up2_dgrad(const float* dz, const void* packed, float* ds, int N, int Dl, int Hl, int Wl, int Cl, int Cout,
                          int terms, const float* dscale, const float* wscale, void* stats_ws, double* stats_out,
+                         int in_blocked /* dz channel-blocked (N, Cout/8, 2Dl, 2Hl, 2Wl, 8): whole lines per request */,
                          void* stream);
 /* weight gradient of the same operator (csrc/norm.hip): G (N, Dl*Hl*Wl, 27, Cout) = 2x2x2 box sums of dz such that
  * dW[tap][ci][co] = sum_m x_low[m][ci] G[m][tap][co] -- one plain matrix product over the low-resolution voxels */
-int kmh_up2_boxsum(const float* dz, float* G, int N, int Dl, int Hl, int Wl, int Cout, void* stream);
+int kmh_up2_boxsum(const float* dz, float* G, int N, int Dl, int Hl, int Wl, int Cout, int in_blocked /* as above */,
+                   void* stream);
 /* C (N, Cl, J) = A^T B per sample over the V low-resolution voxels: A (N, V, Cl) the normalised low tensor, B (N, V, J)
  * the box sums with J = 27 Cout (split-operand MFMA; ascale / bscale = {S, 1/S} of A and B for terms == 2).
  * a_scale / a_shift (N, Cl) | both NULL: A is the RAW low tensor and GroupNorm's affine a_scale[n][c] A + a_shift[n][c]

@@ -71,8 +71,8 @@ PROTOS = {
     "kmh_conv3d_up2_dgrad_pack_bytes": (_sz, [_i, _i, _i]),
     "kmh_conv3d_up2_dgrad_pack_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f]),
     "kmh_conv3d_up2_dgrad_stats_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "kmh_conv3d_up2_dgrad": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
-    "kmh_up2_boxsum": (_i, [_f, _f, _i, _i, _i, _i, _i, _f]),
+    "kmh_conv3d_up2_dgrad": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f]),
+    "kmh_up2_boxsum": (_i, [_f, _f, _i, _i, _i, _i, _i, _i, _f]),
     "kmh_up2_wgrad_gemm_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "kmh_up2_wgrad_gemm": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "kmh_conv3d_up2_pack_bytes": (_sz, [_i, _i, _i]),

@@ -300,12 +300,12 @@ def first_layer_grads(x, scale, shift, mr, gamma, weight, dy, ymask, N, D, H, W,
 
 
 def conv3_up2_dgrad(dz: Tensor, weight: Tensor, Cs: int, Cl: int, dscale: Optional[Tensor] = None,
-                    stats_out: Optional[Tensor] = None) -> Tensor:
+                    stats_out: Optional[Tensor] = None, dz_blocked: bool = False) -> Tensor:
     """dz (N,D,H,W,Cout), weight (Cout, Cs+Cl, 3,3,3) -> (N,D/2,H/2,W/2,Cl): for every low voxel the sum over its 8
     children of the data gradient with respect to the nearest-x2 upsampled channels [Cs, Cs+Cl) -- computed at low
     resolution with 64 pre-summed taps (csrc/conv_bf.hip: conv3_up2_dgrad)."""
     lib = _lib.load()
-    N, D, H, W, Cout = dz.shape
+    N, D, H, W, Cout = dz.shape      # (a channel-blocked dz keeps the dense tensor's nominal shape)
     terms = _TERMS[CONV_MODE]
     wsu = None
     if terms == 2:
@@ -322,8 +322,8 @@ def conv3_up2_dgrad(dz: Tensor, weight: Tensor, Cs: int, Cl: int, dscale: Option
     if stats_out is not None:        # (N, Cl, 2) float64: per-channel (sum, sum of squares) of ds, from the epilogue
         sws = workspace(int(lib.kmh_conv3d_up2_dgrad_stats_ws_bytes(N, D // 2, H // 2, W // 2, Cl)), dz.device, "convstats")
     check(lib.kmh_conv3d_up2_dgrad(_p(dz), _p(pk), _p(ds), N, D // 2, H // 2, W // 2, Cl, Cout, terms,
-                                   _p(dscale if terms == 2 else None), _p(wsu), _p(sws), _p(stats_out), _stream()),
-          "kmh_conv3d_up2_dgrad")
+                                   _p(dscale if terms == 2 else None), _p(wsu), _p(sws), _p(stats_out), int(dz_blocked),
+                                   _stream()), "kmh_conv3d_up2_dgrad")
     return ds
 
 
@@ -574,11 +574,15 @@ class _UpCatConvGCR(torch.autograd.Function):
     children, i.e. interpolate's backward), and GroupNorm's backward is applied to the two halves separately."""
 
     @staticmethod
-    def forward(ctx, skip, low, gamma, beta, weight, num_groups, dy_premasked, dskip_lazy=False):
+    def forward(ctx, skip, low, gamma, beta, weight, num_groups, dy_premasked, dskip_lazy=False, dy_blocked=False):
         """dskip_lazy: `skip` is the second output of pool_fork (its gradient goes to _PoolFork.backward and nowhere else):
         the skip half's normalised-input gradient is returned with GroupNorm's backward pending, and the pooling backward
-        applies it while it sums the two gradients (kmh_maxpool3d_bwd_lazy)."""
+        applies it while it sums the two gradients (kmh_maxpool3d_bwd_lazy).
+        dy_blocked: the ONLY consumer of y is a SingleConv called with dx_blocked=True, which returns y's gradient
+        channel-blocked (upcat_blocked_ok): all four gradient kernels then read whole cache lines of it."""
         ctx.dskip_lazy = bool(dskip_lazy)
+        ctx.dy_blocked = bool(dy_blocked)
+        assert not dy_blocked or dy_premasked, "a channel-blocked gradient comes from a SingleConv, i.e. already masked"
         skip, low, gamma, beta, weight = _prep(skip), _prep(low), _prep(gamma), _prep(beta), _prep(weight)
         N, D, H, W, Cs = skip.shape
         Cl, Cout = low.shape[-1], weight.shape[0]
@@ -601,8 +605,11 @@ class _UpCatConvGCR(torch.autograd.Function):
         N, D, H, W, Cs = skip.shape
         Cl, Cout = low.shape[-1], weight.shape[0]
         C, V = Cs + Cl, D * H * W
-        if _is_blocked(dy):
-            raise RuntimeError("keymorph_amd: the fused upsample+concat convolution takes its gradient in (N,D,H,W,C)")
+        blk = ctx.dy_blocked
+        if _is_blocked(dy) != blk:      # a lost or unexpected layout tag would silently scramble channels
+            raise RuntimeError("keymorph_amd: gradient layout mismatch at the fused upsample+concat convolution (channel-"
+                               "blocked tag %s, expected %s); something replaced the gradient tensor (a hook?) -- set "
+                               "KEYMORPH_NO_BLOCKED_GRADS=1 to keep every gradient in (N,D,H,W,C)" % (_is_blocked(dy), blk))
         dy = _prep(dy)
         if not dy_premasked:     # fold the ReLU mask once (this operator's gradient kernels take no mask operand)
             dzm = torch.empty_like(dy)
@@ -614,11 +621,11 @@ class _UpCatConvGCR(torch.autograd.Function):
         # matrix product over the low-resolution voxels per sample (1/8 of the multiply-adds; library fp32 GEMM)
         bhat_s = torch.zeros((N, Cs), dtype=torch.float64, device=dy.device)
         dw_s = conv3_wgrad(skip, scale[:, :Cs].contiguous(), shift[:, :Cs].contiguous(), dy, N, D, H, W, Cs, Cout, False,
-                           xscale=ctx.ascale, dscale=dscale, fold=(weight[:, :Cs].contiguous(), bhat_s))
+                           xscale=ctx.ascale, dscale=dscale, dz_blocked=blk, fold=(weight[:, :Cs].contiguous(), bhat_s))
         if Cout % 4 == 0 and not os.environ.get("KEYMORPH_NO_UPCONV_WGRAD"):
             Vl = V // 8
             boxes = _f32((N, Vl, 27 * Cout), dy.device)
-            check(lib.kmh_up2_boxsum(_p(dy), _p(boxes), N, D // 2, H // 2, W // 2, Cout, _stream()), "kmh_up2_boxsum")
+            check(lib.kmh_up2_boxsum(_p(dy), _p(boxes), N, D // 2, H // 2, W // 2, Cout, int(blk), _stream()), "kmh_up2_boxsum")
             sc_l, sh_l = scale[:, Cs:].contiguous(), shift[:, Cs:].contiguous()   # named: they must outlive the launch
             terms = _TERMS[CONV_MODE]
             dwn = _f32((N, Cl, 27, Cout), dy.device)
@@ -640,16 +647,17 @@ class _UpCatConvGCR(torch.autograd.Function):
                   "kmh_upcat_fwd")
             bhat_l = torch.zeros((N, Cl), dtype=torch.float64, device=dy.device)
             dw_l = conv3_wgrad(xu, scale[:, Cs:].contiguous(), shift[:, Cs:].contiguous(), dy, N, D, H, W, Cl, Cout,
-                               False, xscale=ctx.ascale, dscale=dscale, fold=(weight[:, Cs:].contiguous(), bhat_l))
+                               False, xscale=ctx.ascale, dscale=dscale, dz_blocked=blk,
+                               fold=(weight[:, Cs:].contiguous(), bhat_l))
             del xu
         dw = torch.cat([dw_s, dw_l], dim=1)
         bhat = torch.cat([bhat_s, bhat_l], dim=1)
         # data gradient: skip channels at full resolution (27 taps), upsampled channels at low resolution (64 taps)
         dst_s = torch.empty((N, Cs, 2), dtype=torch.float64, device=dy.device)
         dxn_s = conv3_raw(dy, None, None, pack_weight(weight[:, :Cs].contiguous(), True), None, N, D, H, W, Cout, Cs,
-                          False, False, ascale=dscale, stats_out=dst_s)
+                          False, False, ascale=dscale, stats_out=dst_s, in_blocked=blk)
         dst_l = torch.empty((N, Cl, 2), dtype=torch.float64, device=dy.device)
-        dsum_l = conv3_up2_dgrad(dy, weight, Cs, Cl, dscale, stats_out=dst_l)
+        dsum_l = conv3_up2_dgrad(dy, weight, Cs, Cl, dscale, stats_out=dst_l, dz_blocked=blk)
         dstats = torch.cat([dst_s, dst_l], dim=1)
         c123 = _f32((N, C, 3), dy.device)
         dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)
@@ -684,11 +692,19 @@ class _UpCatConvGCR(torch.autograd.Function):
                                        _stream()), "kmh_gn_bwd_apply")
             dlow = dsum_l
             _tag_grad_scale(dlow, sc_l)
-        return dskip, dlow, dgamma, dbeta, dw, None, None, None
+        return dskip, dlow, dgamma, dbeta, dw, None, None, None, None
+
+
+def upcat_blocked_ok(skip, low, Cout) -> bool:
+    """May the fused operator's OUTPUT gradient arrive channel-blocked?  (the skip half's 27-tap weight gradient must take
+    that layout -- grad_blocked_ok -- and the upsampled half goes through the box sums, Cout % 8 == 0.)"""
+    N, D, H, W, Cs = skip.shape
+    return (torch.is_grad_enabled() and Cout % 8 == 0 and not os.environ.get("KEYMORPH_NO_UPCONV_WGRAD")
+            and not os.environ.get("KEYMORPH_NO_BLOCKED_UPCAT") and grad_blocked_ok(N, D, H, W, Cs, Cout))
 
 
 def upcat_conv_gcr(skip, low, gamma, beta, weight, num_groups: int, dy_premasked: bool = False,
-                   dskip_lazy: bool = False) -> Tensor:
+                   dskip_lazy: bool = False, dy_blocked: bool = False) -> Tensor:
     if dskip_lazy:
         # the hand-off is a contract between THIS operator's backward and pool_fork's: record it on pool_fork's node, so that
         # its backward can tell "no tag because nothing was pending" from "the tag was lost on the way" (a hook, retain_grad
@@ -698,7 +714,7 @@ def upcat_conv_gcr(skip, low, gamma, beta, weight, num_groups: int, dy_premasked
             node._kmh_expect_lazy = True
         else:                          # not pool_fork's second output after all: apply GroupNorm's backward here
             dskip_lazy = False
-    y, ystats = _UpCatConvGCR.apply(skip, low, gamma, beta, weight, num_groups, dy_premasked, dskip_lazy)
+    y, ystats = _UpCatConvGCR.apply(skip, low, gamma, beta, weight, num_groups, dy_premasked, dskip_lazy, dy_blocked)
     _tag_stats(y, ystats)
     return y
 

@@ -1130,7 +1130,9 @@ __global__ __launch_bounds__(DUP_TPB, TERMS == 2 ? 2 : 3) void conv3_up2_dgrad_k
     const float* __restrict__ dz /* (N,2Dl,2Hl,2Wl,Cout) */, const bf16x8* __restrict__ wp,
     float* __restrict__ ds /* (N,Dl,Hl,Wl,Cl) */, int Dl, int Hl, int Wl, int Cl, int CiP, int Cout, int tiles_x,
     int tiles_y, const float* __restrict__ dscale, const float* __restrict__ wscale,
-    double* __restrict__ stats_partial /* (N, bricks, Cl, 2) | NULL: per-brick (sum ds, sum ds^2) of every channel */) {
+    double* __restrict__ stats_partial /* (N, bricks, Cl, 2) | NULL: per-brick (sum ds, sum ds^2) of every channel */,
+    int in_blocked /* dz is channel-blocked (N, Cout/8, 2Dl, 2Hl, 2Wl, 8): a chunk's 32 bytes per voxel are contiguous ACROSS
+                      voxels, whole lines per request instead of 32-byte pieces of 64-byte sectors */) {
   // Workgroup = 16 x 4 x 1 low voxels = two M tiles of (16 x, 2 y); wave = one 32-channel tile of ci, both M tiles.
   // 43.5 KB of LDS; two (f16x3, prefetching: 224 registers) or three (bf16x6) workgroups per CU, whose staging and MFMA
   // phases overlap.
@@ -1170,7 +1172,8 @@ __global__ __launch_bounds__(DUP_TPB, TERMS == 2 ? 2 : 3) void conv3_up2_dgrad_k
         const int lx = v % DHX, ly = (v / DHX) % DHY, lz = v / (DHX * DHY);
         const int gx = 2 * x0 - 1 + lx, gy = 2 * y0 - 1 + ly, gz = 2 * zl - 1 + lz;
         if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D) {
-          const float* p = dn + (((long long)gz * H + gy) * W + gx) * Cout + ch * KC;
+          const long long vox = ((long long)gz * H + gy) * W + gx;
+          const float* p = in_blocked ? dn + ((long long)ch * D * H * W + vox) * KC : dn + vox * Cout + ch * KC;
           if ((Cout & 3) == 0) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -1490,17 +1493,18 @@ KMH_API size_t kmh_conv3d_up2_dgrad_stats_ws_bytes(int N, int Dl, int Hl, int Wl
 /* stats_out (N,Cl,2) doubles | NULL (then stats_ws may be NULL): per-channel (sum ds, sum ds^2), from the epilogue */
 KMH_API int kmh_conv3d_up2_dgrad(const float* dz, const void* packed, float* ds, int N, int Dl, int Hl, int Wl, int Cl,
                                  int Cout, int terms, const float* dscale, const float* wscale, void* stats_ws,
-                                 double* stats_out, void* stream) {
+                                 double* stats_out, int in_blocked, void* stream) {
   if ((terms != 2 && terms != 3) || (terms == 2 && (!dscale || !wscale)) || (stats_out && !stats_ws)) return -22;
+  if (in_blocked && (Cout & 7)) return -22;               // whole 8-channel chunks
   const int CiP = (Cl + 127) & ~127;
   const int tx = ceil_div(Wl, DUX), ty = ceil_div(Hl, DUY);
   dim3 g(tx * ty * Dl * ceil_div(Cl, 128), 1, N);
   hipStream_t s = (hipStream_t)stream;
   double* sp = stats_out ? (double*)stats_ws : nullptr;
   if (terms == 2)
-    conv3_up2_dgrad_kernel<2><<<g, DUP_TPB, 0, s>>>(dz, (const bf16x8*)packed, ds, Dl, Hl, Wl, Cl, CiP, Cout, tx, ty, dscale, wscale, sp);
+    conv3_up2_dgrad_kernel<2><<<g, DUP_TPB, 0, s>>>(dz, (const bf16x8*)packed, ds, Dl, Hl, Wl, Cl, CiP, Cout, tx, ty, dscale, wscale, sp, in_blocked);
   else
-    conv3_up2_dgrad_kernel<3><<<g, DUP_TPB, 0, s>>>(dz, (const bf16x8*)packed, ds, Dl, Hl, Wl, Cl, CiP, Cout, tx, ty, dscale, wscale, sp);
+    conv3_up2_dgrad_kernel<3><<<g, DUP_TPB, 0, s>>>(dz, (const bf16x8*)packed, ds, Dl, Hl, Wl, Cl, CiP, Cout, tx, ty, dscale, wscale, sp, in_blocked);
   if (stats_out)
     kmh_stats::final_kernel<<<dim3(ceil_div(Cl * 2, 256 / kWave), N), 256, 0, s>>>(sp, tx * ty * Dl, Cl, stats_out);
   return KMH_LAUNCH_CHECK();

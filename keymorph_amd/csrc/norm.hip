@@ -916,8 +916,13 @@ KMH_API int kmh_gn_bwd_apply(const float* dxn, const float* x, const float* c123
 // so the correlation becomes ONE plain matrix product over the low-resolution voxels (1/8 of the multiply-adds).  This
 // kernel forms G (N, V_low, 27, Cout) from dz (N, 2Dl, 2Hl, 2Wl, Cout): thread = (low voxel, channel quad), the 4 x 4 x 4
 // window is streamed once and reduced separably (x pairs, then y pairs, then z pairs).
+// address of channels [c, c + 4) of voxel `vox` in one sample of dz: (D,H,W,C), or channel-blocked (C/8, D,H,W, 8)
+__device__ __forceinline__ const float* dz_quad(const float* dn, long long vox, int c, int Cout, long long V, int in_blocked) {
+  return in_blocked ? dn + ((long long)(c >> 3) * V + vox) * 8 + (c & 7) : dn + vox * Cout + c;
+}
+
 __global__ __launch_bounds__(256, 3) void up2_boxsum_kernel(const float* __restrict__ dz, float* __restrict__ G, int Dl,
-                                                            int Hl, int Wl, int Cout) {
+                                                            int Hl, int Wl, int Cout, int in_blocked) {
   // thread = (low voxel, z tap, channel quad): 2 of the window's 4 planes, 9 outputs -- ~100 registers instead of 256
   const int n = blockIdx.y;
   const int cq = Cout >> 2;
@@ -946,7 +951,8 @@ __global__ __launch_bounds__(256, 3) void up2_boxsum_kernel(const float* __restr
           const int ux = 2 * mx - 1 + ix;
           a4[ix] = make_float4(0.f, 0.f, 0.f, 0.f);
           if ((unsigned)ux < (unsigned)W && (unsigned)uy < (unsigned)H && (unsigned)uz < (unsigned)D)
-            a4[ix] = *reinterpret_cast<const float4*>(dn + (((long long)uz * H + uy) * W + ux) * Cout + 4 * q);
+            a4[ix] = *reinterpret_cast<const float4*>(dz_quad(dn, ((long long)uz * H + uy) * W + ux, 4 * q, Cout,
+                                                              (long long)D * H * W, in_blocked));
         }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
@@ -975,7 +981,8 @@ constexpr int BT_HX = 2 * BT_X + 2, BT_HY = 2 * BT_Y + 2, BT_HZ = 2 * BT_Z + 2, 
 constexpr int BT_PLANE = BT_VOX + 1;
 constexpr int BT_TPB = BT_X * BT_Y * BT_Z * 3 * BT_CQ;                                                             // 768
 __global__ __launch_bounds__(BT_TPB) void up2_boxsum_tiled_kernel(const float* __restrict__ dz, float* __restrict__ G, int Dl,
-                                                                  int Hl, int Wl, int Cout, int tiles_x, int tiles_y) {
+                                                                  int Hl, int Wl, int Cout, int tiles_x, int tiles_y,
+                                                                  int in_blocked) {
   __shared__ float4 sx[BT_CQ * BT_PLANE];
   const int n = blockIdx.z, chunk = blockIdx.y, tid = threadIdx.x;
   const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, bz = blockIdx.x / (tiles_x * tiles_y);
@@ -988,7 +995,8 @@ __global__ __launch_bounds__(BT_TPB) void up2_boxsum_tiled_kernel(const float* _
     const int ux = 2 * x0 - 1 + lx, uy = 2 * y0 - 1 + ly, uz = 2 * z0 - 1 + lz, c = (chunk * BT_CQ + q) * 4;
     float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((unsigned)ux < (unsigned)W && (unsigned)uy < (unsigned)H && (unsigned)uz < (unsigned)D && c < Cout)
-      val = *reinterpret_cast<const float4*>(dn + (((long long)uz * H + uy) * W + ux) * Cout + c);
+      val = *reinterpret_cast<const float4*>(dz_quad(dn, ((long long)uz * H + uy) * W + ux, c, Cout, (long long)D * H * W,
+                                                     in_blocked));
     sx[q * BT_PLANE + v] = val;
   }
   __syncthreads();
@@ -1028,19 +1036,19 @@ __global__ __launch_bounds__(BT_TPB) void up2_boxsum_tiled_kernel(const float* _
 /* G (N, Dl*Hl*Wl, 27, Cout) from dz (N, 2Dl, 2Hl, 2Wl, Cout), Cout % 4 == 0 (see the kernel comment): the weight gradient
  * of a 3x3x3 convolution with respect to nearest-x2 upsampled input channels is then x_low^T (Cl x V_low) times G
  * (V_low x 27 Cout) per sample -- one plain matrix product (the host uses the library GEMM). */
-KMH_API int kmh_up2_boxsum(const float* dz, float* G, int N, int Dl, int Hl, int Wl, int Cout, void* stream) {
-  if (Cout & 3) return -22;
+KMH_API int kmh_up2_boxsum(const float* dz, float* G, int N, int Dl, int Hl, int Wl, int Cout, int in_blocked, void* stream) {
+  if ((Cout & 3) || (in_blocked && (Cout & 7))) return -22;
   static const bool plain = getenv("KEYMORPH_BOXSUM_PLAIN") != nullptr;       // A/B runs: the untiled kernel
   if (!plain) {
     const int tx = (Wl + BT_X - 1) / BT_X, ty = (Hl + BT_Y - 1) / BT_Y, tz = (Dl + BT_Z - 1) / BT_Z;
     const int chunks = (Cout + 4 * BT_CQ - 1) / (4 * BT_CQ);
     if ((long long)tx * ty * tz < (1ll << 31) && chunks < 65536 && N < 65536) {
-      up2_boxsum_tiled_kernel<<<dim3(tx * ty * tz, chunks, N), BT_TPB, 0, (hipStream_t)stream>>>(dz, G, Dl, Hl, Wl, Cout, tx, ty);
+      up2_boxsum_tiled_kernel<<<dim3(tx * ty * tz, chunks, N), BT_TPB, 0, (hipStream_t)stream>>>(dz, G, Dl, Hl, Wl, Cout, tx, ty, in_blocked);
       return KMH_LAUNCH_CHECK();
     }
   }
   const long long total = (long long)Dl * Hl * Wl * 3 * (Cout / 4);
-  up2_boxsum_kernel<<<dim3(stream_blocks(total), N), 256, 0, (hipStream_t)stream>>>(dz, G, Dl, Hl, Wl, Cout);
+  up2_boxsum_kernel<<<dim3(stream_blocks(total), N), 256, 0, (hipStream_t)stream>>>(dz, G, Dl, Hl, Wl, Cout, in_blocked);
   return KMH_LAUNCH_CHECK();
 }
 

@@ -103,10 +103,13 @@ class Decoder(nn.Module):
             # are convolved (forward) and differentiated (backward) at low resolution
             # lazy_skip_grad: the skip tensor is pool_fork's second output, so its gradient goes to that node's backward
             # only -- which then applies this operator's GroupNorm backward for the skip half itself (one pass less)
+            # blk: h has one consumer, so its gradient travels channel-blocked (whole cache lines for the four kernels
+            # of the fused operator's backward that read it)
+            blk = B.upcat_blocked_ok(encoder_features, x, c1.conv.out_channels)
             h = B.upcat_conv_gcr(encoder_features, x, c1.groupnorm.weight, c1.groupnorm.bias, c1.conv.weight,
                                  c1._groups, dy_premasked=True,     # its only consumer, SingleConv2, masks its dx
-                                 dskip_lazy=bool(lazy_skip_grad) and B.lazy_skip_ok(encoder_features))
-            return dc.SingleConv2(h, out_premasked)
+                                 dskip_lazy=bool(lazy_skip_grad) and B.lazy_skip_ok(encoder_features), dy_blocked=blk)
+            return dc.SingleConv2(h, out_premasked, dx_blocked=blk)
         return dc(B.upcat(encoder_features, x, lazy_skip_grad), out_premasked)
 
 

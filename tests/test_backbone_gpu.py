@@ -778,7 +778,12 @@ def test_up2_box_sums(cfg):
     dz = torch.randn(N, 2 * ld[0], 2 * ld[1], 2 * ld[2], Cout, generator=g)
     G = torch.full((N, ld[0] * ld[1] * ld[2], 27, Cout), float("nan"), device=DEV)
     dzd = dz.to(DEV)
-    check(lib.kmh_up2_boxsum(_p(dzd), _p(G), N, ld[0], ld[1], ld[2], Cout, _stream()), "kmh_up2_boxsum")
+    check(lib.kmh_up2_boxsum(_p(dzd), _p(G), N, ld[0], ld[1], ld[2], Cout, 0, _stream()), "kmh_up2_boxsum")
+    if Cout % 8 == 0:        # the channel-blocked gradient layout (N, Cout/8, D, H, W, 8): the same sums, bit for bit
+        Gb = torch.full_like(G, float("nan"))
+        dzb = dzd.reshape(N, -1, Cout // 8, 8).permute(0, 2, 1, 3).contiguous()
+        check(lib.kmh_up2_boxsum(_p(dzb), _p(Gb), N, ld[0], ld[1], ld[2], Cout, 1, _stream()), "kmh_up2_boxsum")
+        assert torch.equal(G, Gb)
     pad = F.pad(dz.double().permute(0, 4, 1, 2, 3), (2, 2, 2, 2, 2, 2))            # (N, C, D + 4, H + 4, W + 4): index u + 2
     ref = torch.empty(N, ld[0], ld[1], ld[2], 27, Cout, dtype=torch.float64)
     for kz in range(3):
@@ -821,6 +826,9 @@ def test_up2_data_gradient_at_low_resolution(cfg, mode):
         want = torch.stack([gd.sum(1), (gd * gd).sum(1)], dim=-1)
         close(st, want, 1e-6 * float(want.abs().max()), 1e-6)
         assert torch.equal(got, B.conv3_up2_dgrad(dz, w, Cs, Cl))            # and the gradient itself does not depend on them
+        if Cout % 8 == 0:    # dz channel-blocked, (N, Cout/8, D, H, W, 8) under the dense tensor's nominal shape: bit-identical
+            dzb = dz.reshape(N, -1, Cout // 8, 8).permute(0, 2, 1, 3).contiguous().view(dz.shape)
+            assert torch.equal(got, B.conv3_up2_dgrad(dzb, w, Cs, Cl, dz_blocked=True))
     finally:
         B.set_conv_mode(old)
 
@@ -860,9 +868,21 @@ def test_decoder_block_fused_upsample_concat_conv(cfg, monkeypatch):
             return [y.detach(), skip.grad, low.grad] + [p_.grad.clone() for p_ in dec.parameters()]
 
         monkeypatch.delenv("KEYMORPH_NO_UPCONV_BWD", raising=False)
-        before = B.UPCONV_STATS["calls"]
+        before, hand = B.UPCONV_STATS["calls"], B.BLOCKED_STATS["handoffs"]
         got = run()
         assert B.UPCONV_STATS["calls"] == before + 1
+        # the hidden activation's gradient travels channel-blocked into the fused operator where its kernels take it so
+        # (backbone_ops.upcat_blocked_ok): an internal layout, every gradient BIT-identical with it switched off
+        if B.upcat_blocked_ok(skip0, low0, Cout):
+            assert B.BLOCKED_STATS["handoffs"] == hand + 1, "the blocked hand-off did not run"
+            monkeypatch.setenv("KEYMORPH_NO_BLOCKED_UPCAT", "1")
+            plain = run()
+            monkeypatch.delenv("KEYMORPH_NO_BLOCKED_UPCAT")
+            assert B.BLOCKED_STATS["handoffs"] == hand + 1
+            for a, r in zip(got, plain):
+                assert torch.equal(a, r)
+        else:
+            assert Cout != 64, "the (64 + 128 -> 64) block is the one the headline step hands over blocked"
         monkeypatch.setenv("KEYMORPH_NO_UPCONV_BWD", "1")
         ref = run()
         for a, r in zip(got, ref):

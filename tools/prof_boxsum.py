@@ -13,7 +13,7 @@ for (Dl, Cout) in ((64, 64), (32, 128), (5, 24)):
     dz = torch.randn(*shp, device=dev)
     Dl_, Hl_, Wl_ = shp[1] // 2, shp[2] // 2, shp[3] // 2
     G = torch.full((N, Dl_ * Hl_ * Wl_, 27, Cout), float("nan"), device=dev)
-    f = lambda: check(lib.kmh_up2_boxsum(_p(dz), _p(G), N, Dl_, Hl_, Wl_, Cout, _stream()), "boxsum")
+    f = lambda: check(lib.kmh_up2_boxsum(_p(dz), _p(G), N, Dl_, Hl_, Wl_, Cout, 0, _stream()), "boxsum")
     for _ in range(2): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
