@@ -47,14 +47,24 @@ __device__ __forceinline__ T block_sum(T v, T* scratch) {
 // ONE definition for the system assembly (fits.hip) and for every evaluation (grids.hip): with lambda = 0 and
 // hundreds of clustered keypoints the spline weights reach 1e3..1e4, and a 1-ulp mismatch between the U used
 // to fit and the U used to evaluate shows up as 1e-3 interpolation error at the control points.
-// v_sqrt_f32 / v_log_f32 are 1-ulp hardware approximations, i.e. the same accuracy class as libm's.
+// v_log_f32 is a 1-ulp hardware approximation, i.e. the same accuracy class as libm's.
 // squared distance as ONE explicit fma chain, identical (IEEE fma per component) in scalar and packed form
 // tps_d2 INCLUDES the reference's + 1e-6 under the square root (one fma chain seeded with it)
 __device__ __forceinline__ float tps_d2(float dz, float dy, float dx) { return fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, 1e-6f))); }
-__device__ __forceinline__ float tps_u_from_d2(float d2) {
-  const float r = __builtin_amdgcn_sqrtf(d2);
-  return d2 * (__builtin_amdgcn_logf(r + 1e-6f) * 0.6931471805599453f);
-}
+
+// log(r + e), r = sqrt(d2), e = 1e-6, with ONE transcendental instead of two (v_sqrt/v_rsq and v_log are quarter-rate and
+// were 16 of the 24 issue slots per pair of kernel values):  2 log2(r + e) = log2(d2) + 2 log2(1 + e/r), and e/r <= 1e-3
+// (d2 >= 1e-6), so log2(1 + e/r) = (e/r) / ln 2 to 5e-4 of ITSELF.  e/r comes from the integer reciprocal-square-root
+// estimate (two integer instructions, +-3.4 % of e/r, centred by the 0.98636): the whole correction is <= 2e-6/r in
+// natural-log units and its error <= 3.5e-8/r -- under the rounding of r + 1e-6 in fp32 (6e-8 relative) that the
+// reference's own operation sequence carries, and the fp64 value of log(sqrt(d2) + 1e-6) is what the tests compare with.
+__device__ __forceinline__ float tps_rsq_est(float d2) { return __uint_as_float(0x5f3759dfu - (__float_as_uint(d2) >> 1)); }
+constexpr float kTpsRsqCentre = 0.98636f;                                    // zero-mean estimate
+constexpr float kTpsEpsLog2x2 = 2.0e-6f * 0.98636f / 0.6931471805599453f;    // 2 log2(1 + e/r) = this * estimate
+constexpr float kTpsHalfLn2 = 0.5f * 0.6931471805599453f;
+// 2 log2(r + e)
+__device__ __forceinline__ float tps_log2x2(float d2) { return fmaf(tps_rsq_est(d2), kTpsEpsLog2x2, __builtin_amdgcn_logf(d2)); }
+__device__ __forceinline__ float tps_u_from_d2(float d2) { return (d2 * tps_log2x2(d2)) * kTpsHalfLn2; }
 
 // two-lane version for the packed-fp32 evaluators (v_pk_add/mul/fma_f32): the SAME operation sequence per component
 typedef float kmh_f2 __attribute__((ext_vector_type(2)));
@@ -62,14 +72,18 @@ __device__ __forceinline__ kmh_f2 tps_d2(kmh_f2 dz, kmh_f2 dy, kmh_f2 dx) {
   const kmh_f2 eps = {1e-6f, 1e-6f};
   return __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, eps)));
 }
-// U / ln 2 = d2 * log2(r + 1e-6): the evaluators fold ln 2 into the (per-keypoint) weights instead of every kernel value
-__device__ __forceinline__ kmh_f2 tps_u2_from_d2(kmh_f2 d2) {
-  kmh_f2 r, l;
-  r.x = __builtin_amdgcn_sqrtf(d2.x); r.y = __builtin_amdgcn_sqrtf(d2.y);
-  const kmh_f2 re = r + 1e-6f;
-  l.x = __builtin_amdgcn_logf(re.x); l.y = __builtin_amdgcn_logf(re.y);
-  return d2 * l;
+// (scalars first: hipcc 7.2 mis-reads element 0 when a bit cast is applied to a vector element directly)
+__device__ __forceinline__ kmh_f2 tps_rsq_est2(kmh_f2 d2) {
+  const float a = d2.x, b = d2.y;
+  return kmh_f2{tps_rsq_est(a), tps_rsq_est(b)};
 }
+__device__ __forceinline__ kmh_f2 tps_log2x2(kmh_f2 d2, kmh_f2 y /* tps_rsq_est2(d2) */) {
+  const float a = d2.x, b = d2.y;
+  const kmh_f2 lg = {__builtin_amdgcn_logf(a), __builtin_amdgcn_logf(b)};
+  return __builtin_elementwise_fma(y, kmh_f2{kTpsEpsLog2x2, kTpsEpsLog2x2}, lg);
+}
+// 2 U / ln 2 = d2 * 2 log2(r + 1e-6): the evaluators fold ln 2 / 2 into the (per-keypoint) weights instead of every value
+__device__ __forceinline__ kmh_f2 tps_u2_from_d2(kmh_f2 d2) { return d2 * tps_log2x2(d2, tps_rsq_est2(d2)); }
 
 // XCD-aware work remap (MI355X: 8 XCDs with private 4 MB L2s; the dispatcher places block b on XCD b % 8 --
 // observed behaviour used for SPEED only, any placement is correct).  Returns the linear work item for

@@ -6,7 +6,7 @@
 // once, already flipped to the xyz order grid_sample expects.
 //
 // TPS forward is VALU/transcendental bound (8.6 G (voxel,keypoint) pairs at 256^3 x 512, each
-// one v_sqrt + one v_log + ~14 VALU; 201 MB written, 12 KB read): keypoints + weights live in
+// one v_log (common.h: tps_log2x2) + ~8 VALU; 201 MB written, 12 KB read): keypoints + weights live in
 // LDS and are broadcast-read; each lane owns VPT consecutive voxels.
 // TPS backward is the transposed reduction: each lane owns KPT keypoints (6 accumulators
 // each), voxels + their incoming gradient are staged through LDS and broadcast.
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(TPB) void tps_eval_fwd_kernel(const float* __restri
   const float* cc = ctrl + (long long)n * T * 3;
   for (int t = threadIdx.x; t < T; t += TPB) {
     sc[t] = make_float4(cc[t * 3], cc[t * 3 + 1], cc[t * 3 + 2], 0.f);
-    const float ln2 = 0.6931471805599453f;   // folded into the weights: the loop accumulates w ln2 * (U / ln2)
-    sw[t] = make_float4(th[t * 3] * ln2, th[t * 3 + 1] * ln2, th[t * 3 + 2] * ln2, 0.f);
+    const float hl = kTpsHalfLn2;   // folded into the weights: the loop accumulates (w ln2 / 2) * (2 U / ln2)
+    sw[t] = make_float4(th[t * 3] * hl, th[t * 3 + 1] * hl, th[t * 3 + 2] * hl, 0.f);
   }
   __syncthreads();
   const long long v0 = ((long long)blockIdx.x * TPB + threadIdx.x) * VPT;
@@ -219,6 +219,14 @@ constexpr int BWD_TPB = 256;       // -> 512 keypoints per block pass
 constexpr int VSTAGE = 256;        // voxels staged per LDS refill (one per thread)
 constexpr int VCHUNK = 8192;       // voxels per block
 
+// 2 dU/d(d2) = 2 ln(r + eps) + r / (r + eps), from L = 2 log2(r + eps) and the reciprocal-square-root estimate y:
+// r / (r + eps) = 1 / (1 + t) = 1 - t + O(t^2), t = eps / r = 1e-6 * 0.98636 y <= 1e-3 (t^2 <= 1e-6 of a term of size one)
+__device__ __forceinline__ kmh_f2 tps_du2(kmh_f2 L, kmh_f2 y) {
+  const kmh_f2 ln2 = {0.6931471805599453f, 0.6931471805599453f}, one = {1.f, 1.f};
+  const kmh_f2 mt = {-1.0e-6f * kTpsRsqCentre, -1.0e-6f * kTpsRsqCentre};
+  return __builtin_elementwise_fma(y, mt, __builtin_elementwise_fma(L, ln2, one));
+}
+
 // ROWS (implicit grid with W % VSTAGE == 0): a stage's 256 voxels are one piece of ONE grid row, so dz, dy and the inner
 // links of the distance chain are per-stage constants of the lane's keypoints, and sum f dz = dz sum f (same for dy).
 template <bool EXPLICIT_POINTS, bool ROWS = false>
@@ -282,17 +290,12 @@ __global__ __launch_bounds__(BWD_TPB) void tps_eval_bwd_kernel(
         const float4 gg = sg[j];
         const kmh_f2 dx = cx - px;
         const kmh_f2 d2 = __builtin_elementwise_fma(dx, dx, zy);      // == tps_d2(dz, dy, dx)
-        kmh_f2 rs, L;
-        rs.x = __builtin_amdgcn_rsqf(d2.x); rs.y = __builtin_amdgcn_rsqf(d2.y);
-        const kmh_f2 r = d2 * rs;
-        const kmh_f2 re = r + 1e-6f;
-        L.x = __builtin_amdgcn_logf(re.x); L.y = __builtin_amdgcn_logf(re.y);
+        const kmh_f2 y = tps_rsq_est2(d2);
+        const kmh_f2 L = tps_log2x2(d2, y);                         // 2 log2(r + eps), common.h
         const kmh_f2 u = d2 * L;
         aw[0] += u * gg.x; aw[1] += u * gg.y; aw[2] += u * gg.z;
         const kmh_f2 s = wz * gg.x + wy * gg.y + wx * gg.z;
-        const kmh_f2 tt = rs * 1e-6f;
-        const kmh_f2 f = s * __builtin_elementwise_fma(L, kmh_f2{2.f * 0.6931471805599453f, 2.f * 0.6931471805599453f},
-                                                       1.f - tt + tt * tt);
+        const kmh_f2 f = s * tps_du2(L, y);
         fs += f;
         ac[2] += f * dx;
       }
@@ -303,21 +306,15 @@ __global__ __launch_bounds__(BWD_TPB) void tps_eval_bwd_kernel(
     for (int j = 0; j < cnt; ++j) {
       const float4 pp = sp[j];
       const float4 gg = sg[j];
-      // both keypoints of the lane at once (v_pk_*_f32); two transcendentals per (voxel, keypoint): rsq and log
+      // both keypoints of the lane at once (v_pk_*_f32); one transcendental per (voxel, keypoint): log2(d2)
       const kmh_f2 dz = cz - pp.x, dy = cy - pp.y, dx = cx - pp.z;
       const kmh_f2 d2 = tps_d2(dz, dy, dx);                       // includes the + 1e-6
-      kmh_f2 rs, L;
-      rs.x = __builtin_amdgcn_rsqf(d2.x); rs.y = __builtin_amdgcn_rsqf(d2.y);
-      const kmh_f2 r = d2 * rs;                                   // sqrt(d2) to 1-2 ulp (gradients only)
-      const kmh_f2 re = r + 1e-6f;
-      L.x = __builtin_amdgcn_logf(re.x); L.y = __builtin_amdgcn_logf(re.y);   // log2: ln 2 is applied once, after the loop
+      const kmh_f2 y = tps_rsq_est2(d2);
+      const kmh_f2 L = tps_log2x2(d2, y);                           // 2 log2(r + eps): ln 2 / 2 is applied once, after the loop
       const kmh_f2 u = d2 * L;
       aw[0] += u * gg.x; aw[1] += u * gg.y; aw[2] += u * gg.z;
-      // dU/d(d2) = ln r' + r / (2 (r + eps));  r / (r + eps) = 1 / (1 + eps/r) = 1 - t + t^2 - ...,  t = eps rs <= 1e-3
       const kmh_f2 s = wz * gg.x + wy * gg.y + wx * gg.z;
-      const kmh_f2 tt = rs * 1e-6f;
-      const kmh_f2 f = s * __builtin_elementwise_fma(L, kmh_f2{2.f * 0.6931471805599453f, 2.f * 0.6931471805599453f},
-                                                     1.f - tt + tt * tt);
+      const kmh_f2 f = s * tps_du2(L, y);
       ac[0] += f * dz; ac[1] += f * dy; ac[2] += f * dx;
     }
   }
@@ -325,8 +322,7 @@ __global__ __launch_bounds__(BWD_TPB) void tps_eval_bwd_kernel(
   for (int k = 0; k < KPT; ++k) {
     if (tk[k] < T) {
       float* o = partial + (((long long)n * nchunk + chunk) * T + tk[k]) * 6;
-      const float ln2 = 0.6931471805599453f;
-      o[0] = aw[0][k] * ln2; o[1] = aw[1][k] * ln2; o[2] = aw[2][k] * ln2;
+      o[0] = aw[0][k] * kTpsHalfLn2; o[1] = aw[1][k] * kTpsHalfLn2; o[2] = aw[2][k] * kTpsHalfLn2;
       o[3] = ac[0][k]; o[4] = ac[1][k]; o[5] = ac[2][k];
     }
   }

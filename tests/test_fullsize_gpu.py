@@ -226,7 +226,9 @@ def test_two_pairs_per_gpu_equal_two_single_pairs(world):
         km.zero_grad(set_to_none=True)
         km.eval()
     for i, (pi, gi) in enumerate(singles):
-        close(pb[[i, 2 + i]], pi, 2e-6)
+        # (not bit-equal: the f16x3 split takes ONE range scale per tensor, i.e. over the whole batch, so a sample's rounding
+        # depends on its batch mates; observed 1.5e-6 .. 2.2e-6 over the weights the earlier tests of this file leave behind)
+        close(pb[[i, 2 + i]], pi, 4e-6)
         close(grid_b[i:i + 1], ls[i][1], 2e-4)
     gs = singles[0][1] + singles[1][1]
     rel = float((gb - gs).norm() / gs.norm())
