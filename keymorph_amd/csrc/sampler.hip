@@ -686,6 +686,263 @@ __global__ __launch_bounds__(TPB) void warp_dice_sums_kernel(
   }
 }
 
+// Multi-channel bilinear warp (align_img of a one-hot segmentation, keymorph/utils.py:14-21 under
+// scripts/pairwise_register_eval.py).  sample_fwd_lc_kernel walks 4-row x 256 chunks of ONE output plane and pays one memory
+// round trip per (sub-pass, channel): 1.8 ms at 14 x 256^3 (1.1 TB/s; PMC: L2 hit rate 37 %, FETCH_SIZE 3.4x the algorithmic
+// reads).  Here a workgroup owns a compact 16 x 8 x 8 output TILE -- under a rotation about any axis its source box stays
+// ~22 x 18 x 17, where a 32 x 8 x 4 tile's does not fit the LDS box below (measured: 1.06 vs 1.73 ms on bench.py's
+// three-axis affine grid, 0.94 vs 0.88 ms on a one-axis rotation) -- tiles are walked x-fastest in one contiguous range per
+// XCD, and the machinery of the Dice kernels does the rest: persistent blocks, the next tile's grid rows prefetched into
+// registers, 32-bit corner offsets, buffer loads, range-checked stores.
+// The blend is blend8 on the same corner values (a corner past the far border has weight 0 there and reads 0 here):
+// bit-equal to the single-channel kernel (tests/test_ops_gpu.py::test_multichannel_sampler_equals_per_channel).
+#ifndef KMH_MT_X
+#define KMH_MT_X 16
+#define KMH_MT_Y 8
+#define KMH_MT_Z 8
+#endif
+constexpr int MT_X = KMH_MT_X, MT_Y = KMH_MT_Y, MT_Z = KMH_MT_Z;
+static_assert(MT_X * MT_Y * MT_Z == TPB * PASSES && (MT_X & (MT_X - 1)) == 0 && (MT_Y & (MT_Y - 1)) == 0 && MT_X % 4 == 0,
+              "1024-voxel tiles with power-of-two sides");
+constexpr int MT_LX = __builtin_ctz(MT_X), MT_LXY = __builtin_ctz(MT_X * MT_Y);
+constexpr int MT_Q4 = MT_X * 3 / 4;                  // 16-byte pieces of a tile row of the grid
+// tile voxel l = tid + pass * 256  ->  (l & (MT_X-1), (l >> MT_LX) & (MT_Y-1), l >> MT_LXY)
+// BOX path: the tile's corners live in a small source box (identity-like grid: 34 x 10 x 5); per channel the workgroup copies
+// that box into LDS with coalesced 4-byte loads (prefetched into registers one channel ahead) and the 8 corners of a voxel
+// come from four ds_read2_b32 instead of four 64-lane gathers of 4-byte-aligned 8-byte pairs (10 % faster than the global
+// gathers of the same tile walk, 0.88 vs 0.97 ms at 14 x 256^3; with loads and stores compiled out the kernel still takes
+// 0.41 ms: ~25 instructions per voxel and channel at 3 waves per SIMD are what bounds it, not the memory system).
+// A tile whose box does not fit (strong zoom-out / shear: more than MB_PITCH columns or MB_ROWS rows) takes the global gathers.
+constexpr int MB_PITCH = MT_X + 8, MB_CAP = 6144;
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m, 64); v = o < v ? o : v; }
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+  return v;
+}
+
+struct BoxGeom { int x0, y0, z0, nx, ny, nrows; };
+constexpr int MB_RPS = TPB / MB_PITCH;               // 6 box rows copied per step (240 of the 256 threads)
+constexpr int MB_KMAX = 26;                          // steps: up to 156 rows
+constexpr int MB_ROWS = MB_CAP / MB_PITCH;           // 153
+
+// one channel loop of a tile through the LDS box; KR = box rows per thread (registers of the one-channel-ahead prefetch).
+// rowoff[r]: byte offset (inside a channel plane) of box row r's first float, or >= plane_bytes for rows past the box.
+// (16-byte copies -- 7 instead of 26 loads per thread and channel -- measured no faster: the kernel is bound by the ~25
+// instructions per voxel and channel of the gather + blend + store, not by the copy.)
+template <int KR>
+__device__ __forceinline__ void mc_box_channels(const float* __restrict__ x, float* __restrict__ out, int n, int C,
+                                                long long plane, long long ovox, unsigned plane_bytes, unsigned out_bytes,
+                                                float* box, const unsigned* rowoff, int tid, const BoxGeom& g, int W,
+                                                const unsigned (&lo)[PASSES][4], const float (&fr)[PASSES][3],
+                                                const unsigned (&oo)[PASSES]) {
+  const int r0 = tid / MB_PITCH, ix = tid - r0 * MB_PITCH;
+  // idle lanes, columns past the box and the column past the volume's last one read 0 (x0 = W - 1: the pair's second value
+  // has weight fx = 0, and the next row's first voxel there could turn 0 * Inf into a NaN the reference does not produce)
+  const unsigned colb = (r0 < MB_RPS && ix < g.nx && g.x0 + ix < W) ? 4u * (unsigned)ix : plane_bytes;
+  float R[KR];
+  auto prefetch = [&](int c) {
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + ((long long)n * C + c) * plane, plane_bytes);
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+      R[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(rowoff[r0 + k * MB_RPS] + colb), 0, 0));
+  };
+  prefetch(0);
+#pragma unroll 1
+  for (int c = 0; c < C; ++c) {
+    __syncthreads();                                  // the previous channel's gathers are done
+    if (r0 < MB_RPS) {
+#pragma unroll
+      for (int k = 0; k < KR; ++k) box[tid + k * (MB_RPS * MB_PITCH)] = R[k];
+    }
+    __syncthreads();
+    if (c + 1 < C) prefetch(c + 1);                   // the next channel's box: in flight under this channel's gathers
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + ((long long)n * C + c) * ovox, out_bytes);
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float2 r;
+        __builtin_memcpy(&r, box + lo[u][k], sizeof(float2));      // 4-byte aligned pair: ds_read2_b32
+        v[2 * k] = r.x; v[2 * k + 1] = r.y;
+      }
+      const float o = blend8f(v, fr[u][0], fr[u][1], fr[u][2]);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro, (int)oo[u], 0, 0);      // dropped past the volume
+    }
+  }
+}
+
+template <int MC_ILP>
+__global__ __launch_bounds__(TPB, 3) void sample_fwd_mc_kernel(
+    const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ out, int C, int D, int H, int W,
+    int Do, int Ho, int Wo, int ntx, int nty, int ntile, int use_box) {
+  __shared__ __attribute__((aligned(16))) float sg[TPB * PASSES * 3];
+  __shared__ __attribute__((aligned(16))) float box[MB_KMAX * MB_RPS * MB_PITCH];
+  __shared__ unsigned rowoff[MB_KMAX * MB_RPS + MB_RPS];
+  __shared__ int sred[TPB / kWave][6];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const long long plane = (long long)D * H * W, ovox = (long long)Do * Ho * Wo;
+  const unsigned plane_bytes = (unsigned)(plane * 4), out_bytes = (unsigned)(ovox * 4);
+  const float* gbase = grid + (long long)n * ovox * 3;
+  const int lx = tid & (MT_X - 1), ly = (tid >> MT_LX) & (MT_Y - 1), lz = tid >> MT_LXY, dzp = TPB >> MT_LXY;      // pass u: plane lz + u * dzp
+  // the tile's 32 grid rows (96 floats each) as 768 float4: thread t owns numbers t, t + 256, t + 512
+  auto row_src = [&](int tile, int idx, bool& ok) -> const float* {
+    const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+    const int r = idx / MT_Q4, q4 = idx - r * MT_Q4;
+    const int z = tz * MT_Z + r / MT_Y, y = ty * MT_Y + (r & (MT_Y - 1));
+    ok = z < Do && y < Ho;
+    return gbase + (((long long)z * Ho + y) * Wo + tx * MT_X) * 3 + q4 * 4;
+  };
+  auto tile_fast = [&](int tile) -> bool {       // whole 32-voxel rows, 16-byte aligned: Wo % 4 == 0 and the tile inside in x
+    const int tx = tile % ntx;
+    return (Wo & 3) == 0 && tx * MT_X + MT_X <= Wo && ((reinterpret_cast<unsigned long long>(gbase) & 15) == 0);
+  };
+  auto fetch = [&](int tile, GridRows& g) {
+    bool ok;
+    const float* p0 = row_src(tile, tid, ok);
+    g.a = ok ? *reinterpret_cast<const float4*>(p0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* p1 = row_src(tile, tid + TPB, ok);
+    g.b = ok ? *reinterpret_cast<const float4*>(p1) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* p2 = row_src(tile, tid + 2 * TPB, ok);
+    g.c = ok ? *reinterpret_cast<const float4*>(p2) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  const ChunkWalk cw = chunk_walk(blockIdx.x, gridDim.x, ntile);
+  int tile = cw.cur;
+  GridRows nxt = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  bool nfast = false;
+  if (tile < cw.end) {
+    nfast = tile_fast(tile);
+    if (nfast) fetch(tile, nxt);
+  }
+#pragma unroll 1
+  for (; tile < cw.end; tile += cw.step) {
+    const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+    const int x0 = tx * MT_X, y0 = ty * MT_Y, z0 = tz * MT_Z;
+    __syncthreads();                                  // the previous tile's readers of sg / box are done
+    if (nfast) {
+      float4* d4 = reinterpret_cast<float4*>(sg);
+      d4[tid] = nxt.a; d4[tid + TPB] = nxt.b; d4[tid + 2 * TPB] = nxt.c;
+    } else {                                          // edge tile / unaligned rows: element by element, zeros outside
+      for (int e = tid; e < TPB * PASSES * 3; e += TPB) {
+        const int l = e / 3, k = e - l * 3;
+        const int xx = x0 + (l & (MT_X - 1)), yy = y0 + ((l >> MT_LX) & (MT_Y - 1)), zz = z0 + (l >> MT_LXY);
+        sg[e] = (xx < Wo && yy < Ho && zz < Do) ? gbase[(((long long)zz * Ho + yy) * Wo + xx) * 3 + k] : 0.f;
+      }
+    }
+    __syncthreads();
+    {                                                 // the next tile's rows: in flight under this tile's gathers
+      const int t2 = tile + cw.step;
+      if (t2 < cw.end) {
+        nfast = tile_fast(t2);
+        if (nfast) fetch(t2, nxt);
+      }
+    }
+    const bool in_xy = x0 + lx < Wo && y0 + ly < Ho;
+    bool boxed = false;
+    if (use_box) {
+      // corners of the lane's 4 voxels (one per tile plane) and the box that holds every live corner of the tile
+      int cx[PASSES], cy[PASSES], cz[PASSES], cy1[PASSES], cz1[PASSES];
+      float fr[PASSES][3];
+      unsigned oo[PASSES];
+      int mn[3] = {1 << 30, 1 << 30, 1 << 30}, mx[3] = {-1, -1, -1};
+#pragma unroll
+      for (int u = 0; u < PASSES; ++u) {
+        const int l = tid + u * TPB, z = z0 + lz + u * dzp;
+        const Tap t = make_tap(sg[l * 3], sg[l * 3 + 1], sg[l * 3 + 2], D, H, W);
+        const bool live = in_xy && z < Do;
+        cx[u] = t.x0; cy[u] = t.y0; cz[u] = t.z0;      // (the pair of x0 = W - 1 takes a zero from past the box's last column)
+        cy1[u] = t.y0 + 1 < H ? t.y0 + 1 : t.y0; cz1[u] = t.z0 + 1 < D ? t.z0 + 1 : t.z0;
+        fr[u][0] = t.fx; fr[u][1] = t.fy; fr[u][2] = t.fz;
+        oo[u] = live ? 4u * (unsigned)(((long long)z * Ho + (y0 + ly)) * Wo + (x0 + lx)) : 0xfffffffcu;
+        if (live) {
+          mn[0] = cx[u] < mn[0] ? cx[u] : mn[0]; mx[0] = cx[u] + 1 > mx[0] ? cx[u] + 1 : mx[0];
+          mn[1] = cy[u] < mn[1] ? cy[u] : mn[1]; mx[1] = cy1[u] > mx[1] ? cy1[u] : mx[1];
+          mn[2] = cz[u] < mn[2] ? cz[u] : mn[2]; mx[2] = cz1[u] > mx[2] ? cz1[u] : mx[2];
+        } else {            // a dead lane's corners sit on the box origin (filled in below)
+          cx[u] = cy[u] = cz[u] = cy1[u] = cz1[u] = -1;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { mn[k] = wave_min_i(mn[k]); mx[k] = wave_max_i(mx[k]); }
+      if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { sred[tid >> 6][k] = mn[k]; sred[tid >> 6][3 + k] = mx[k]; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int w = 0; w < TPB / kWave; ++w) {
+          mn[k] = sred[w][k] < mn[k] ? sred[w][k] : mn[k];
+          mx[k] = sred[w][3 + k] > mx[k] ? sred[w][3 + k] : mx[k];
+        }
+      }
+      BoxGeom g;
+      g.x0 = mn[0]; g.y0 = mn[1]; g.z0 = mn[2];
+      g.nx = mx[0] - mn[0] + 1; g.ny = mx[1] - mn[1] + 1;
+      g.nrows = g.ny * (mx[2] - mn[2] + 1);
+      boxed = g.nx <= MB_PITCH && g.nrows <= MB_ROWS;      // uniform
+      if (boxed) {
+        unsigned lo[PASSES][4];
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+          const bool dead = cx[u] < 0;
+          const int ax = dead ? 0 : cx[u] - g.x0, ay = dead ? 0 : cy[u] - g.y0, ay1 = dead ? 0 : cy1[u] - g.y0;
+          const int az = dead ? 0 : cz[u] - g.z0, az1 = dead ? 0 : cz1[u] - g.z0;
+          lo[u][0] = (unsigned)((az * g.ny + ay) * MB_PITCH + ax); lo[u][1] = (unsigned)((az * g.ny + ay1) * MB_PITCH + ax);
+          lo[u][2] = (unsigned)((az1 * g.ny + ay) * MB_PITCH + ax); lo[u][3] = (unsigned)((az1 * g.ny + ay1) * MB_PITCH + ax);
+        }
+        // row offsets of the box (rows past it: out of range)
+        for (int r = tid; r < MB_KMAX * MB_RPS + MB_RPS; r += TPB) {
+          const int iz = (int)(((float)r + 0.5f) / (float)g.ny), iy = r - iz * g.ny;      // exact: r, ny < 2^10
+          rowoff[r] = r < g.nrows ? 4u * (unsigned)(((g.z0 + iz) * H + (g.y0 + iy)) * W + g.x0) : plane_bytes;
+        }
+        __syncthreads();
+        if (g.nrows <= 10 * MB_RPS)
+          mc_box_channels<10>(x, out, n, C, plane, ovox, plane_bytes, out_bytes, box, rowoff, tid, g, W, lo, fr, oo);
+        else if (g.nrows <= 18 * MB_RPS)
+          mc_box_channels<18>(x, out, n, C, plane, ovox, plane_bytes, out_bytes, box, rowoff, tid, g, W, lo, fr, oo);
+        else
+          mc_box_channels<MB_KMAX>(x, out, n, C, plane, ovox, plane_bytes, out_bytes, box, rowoff, tid, g, W, lo, fr, oo);
+      }
+    }
+    if (boxed) continue;
+#pragma unroll 1
+    for (int j0 = 0; j0 < PASSES; j0 += MC_ILP) {
+      TapB q[MC_ILP];
+      unsigned oo[MC_ILP];                            // byte offset of the lane's output voxel inside a channel plane
+#pragma unroll
+      for (int u = 0; u < MC_ILP; ++u) {
+        const int l = tid + (j0 + u) * TPB;
+        const int z = z0 + lz + (j0 + u) * dzp;
+        q[u] = make_tapb(make_tap(sg[l * 3], sg[l * 3 + 1], sg[l * 3 + 2], D, H, W), D, H, W);
+        const bool live = in_xy && z < Do;
+        oo[u] = live ? 4u * (unsigned)(((long long)z * Ho + (y0 + ly)) * Wo + (x0 + lx)) : 0xfffffffcu;   // dropped by the range check
+        if (!live) q[u].o00 = q[u].o01 = q[u].o10 = q[u].o11 = plane_bytes;      // reads zeros
+      }
+#pragma unroll 2
+      for (int c = 0; c < C; ++c) {
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + ((long long)n * C + c) * plane, plane_bytes);
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + ((long long)n * C + c) * ovox, out_bytes);
+        float v[MC_ILP][8];
+#pragma unroll
+        for (int u = 0; u < MC_ILP; ++u) gather8_b(rx, q[u], v[u]);
+#pragma unroll
+        for (int u = 0; u < MC_ILP; ++u) {
+          const float o = blend8f(v[u], q[u].fx, q[u].fy, q[u].fz);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro, (int)oo[u], 0, 0);
+        }
+      }
+    }
+  }
+}
+
 // partial (N, nb, C, 3) -> sums (N*C, 3) floats: one wave per (n, c, k), fixed order
 __global__ __launch_bounds__(TPB) void warp_dice_final_kernel(const double* __restrict__ partial, int nb, int C, int total,
                                                               float* __restrict__ sums) {
@@ -1068,6 +1325,24 @@ KMH_API int kmh_grid_sample3d_fwd(const float* x, const float* grid, float* out,
   const long long ovox = (long long)Do * Ho * Wo;
   dim3 g(ceil_div(ovox, (long long)TPB * VPT), N);
   hipStream_t s = (hipStream_t)stream;
+  // C >= 2, bilinear: the persistent tiled multi-channel kernel (KMH_SAMPLER_MC=0: the lc kernel; KMH_SAMPLER_MC_MINC=1: also C = 1)
+  static const int mc = getenv("KMH_SAMPLER_MC") ? atoi(getenv("KMH_SAMPLER_MC")) : 4;
+  static const int minc = getenv("KMH_SAMPLER_MC_MINC") ? atoi(getenv("KMH_SAMPLER_MC_MINC")) : 2;
+  if (mode == 0 && C >= minc && mc && lane_contiguous_ok(D, H, W) && (long long)D * H * W < (1ll << 30) && ovox < (1ll << 30)) {
+    const int ntx = (Wo + MT_X - 1) / MT_X, nty = (Ho + MT_Y - 1) / MT_Y, ntz = (Do + MT_Z - 1) / MT_Z;
+    const long long nt = (long long)ntx * nty * ntz;
+    if (nt < (1ll << 30)) {
+      static const int capa = getenv("KMH_MC_BLOCKS") ? atoi(getenv("KMH_MC_BLOCKS")) : 2048;   // ~ resident blocks of the chip
+      long long nb = (capa / N) & ~7;                  // a multiple of 8 per sample row: blockIdx.x % 8 is the XCD
+      if (nb < 8) nb = 8;
+      if (nb > nt) nb = nt;
+      const dim3 gm((unsigned)nb, N);
+      static const int use_box = getenv("KMH_SAMPLER_BOX") ? atoi(getenv("KMH_SAMPLER_BOX")) : 1;
+      if (mc == 2) sample_fwd_mc_kernel<2><<<gm, TPB, 0, s>>>(x, grid, out, C, D, H, W, Do, Ho, Wo, ntx, nty, (int)nt, use_box);
+      else sample_fwd_mc_kernel<4><<<gm, TPB, 0, s>>>(x, grid, out, C, D, H, W, Do, Ho, Wo, ntx, nty, (int)nt, use_box);
+      return KMH_LAUNCH_CHECK();
+    }
+  }
   if (lane_contiguous_ok(D, H, W)) {
     if (mode == 0)
       sample_fwd_lc_kernel<0, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox);

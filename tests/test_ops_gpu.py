@@ -51,6 +51,39 @@ def test_grid_sample_fwd_bwd(shape):
     close(ops().grid_sample3d(x.to(DEV), grid.to(DEV), "nearest"), O.align_img(grid, x, "nearest"), 0)
 
 
+@pytest.mark.parametrize("kind", ["random", "affine", "zoom_in", "border"])
+def test_multichannel_sampler_equals_per_channel(kind):
+    """C >= 2 bilinear warps run sample_fwd_mc_kernel (persistent 16 x 8 x 8 tiles; per channel the tile's source box goes
+    through LDS, tiles whose box does not fit gather from memory; align_img of a one-hot segmentation,
+    keymorph/utils.py:14-21): bit-equal to warping the channels one by one (the single-channel kernel) and within 3e-6 of
+    the oracle -- for a random grid (every tile takes the memory gathers), a three-axis affine grid (box path, ragged edge
+    tiles), a zoom-in (tiny boxes), and a grid that leaves the volume on every side (clipped corners, x0 = W - 1 pairs)."""
+    from keymorph_amd import synthetic
+    from keymorph_amd.transformations import AffineTransform
+    g = gen(8)
+    x = torch.rand(2, 5, 36, 45, 52, generator=g)
+    x[0, 1, :, :, 0] = float("inf")          # a column the x0 = W - 1 pairs must not touch through the next row's first voxel
+    if kind == "random":
+        grid = torch.rand(2, 19, 33, 47, 3, generator=g) * 2.4 - 1.2
+    else:
+        mats = torch.cat([synthetic.random_affine_matrix(s_, DEV) for s_ in (3, 4)])
+        grid = AffineTransform(matrix=mats, dim=3).get_flow_field((2, 1, 35, 41, 50)).contiguous().cpu()
+        if kind == "zoom_in":
+            grid = grid * 0.3
+        if kind == "border":
+            grid = grid * 1.5 + 0.2
+    xd, gd = x.to(DEV), grid.to(DEV)
+    out = ops().grid_sample3d(xd, gd)
+    for c in range(x.shape[1]):
+        one = ops().grid_sample3d(xd[:, c:c + 1].contiguous(), gd)
+        same = (out[:, c:c + 1] == one) | (torch.isnan(one) & torch.isnan(out[:, c:c + 1]))
+        assert bool(same.all()), (kind, c, int((~same).sum()))
+    ref = O.align_img(grid, x)
+    ok = torch.isfinite(ref)
+    close(torch.where(ok, out.cpu(), torch.zeros(())), torch.where(ok, ref, torch.zeros(())), 3e-6)      # (steep grids: the coordinate rounding)
+    assert bool((torch.isfinite(out.cpu()) == ok).all())          # and infinities / NaNs exactly where the reference has them
+
+
 def test_grid_sample_golden():
     o = golden("ops_small.npz")
     x, grid = T(o["warp_x"]).to(DEV), T(o["warp_grid"]).to(DEV).requires_grad_(True)

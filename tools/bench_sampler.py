@@ -2,6 +2,8 @@
 import os, sys, math, torch
 sys.path.insert(0, '.')
 from keymorph_amd import _lib
+if os.environ.get("KMH_LIB"):
+    _lib.LIBPATH = os.environ["KMH_LIB"]
 lib = _lib.load()
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 dev = "cuda"
@@ -13,6 +15,10 @@ zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
 c, s_ = math.cos(0.2), math.sin(0.2)
 grid = torch.stack([1.05 * (c * xx - s_ * yy) + 0.03, 0.95 * (s_ * xx + c * yy) - 0.02, 1.1 * zz + 0.05 * xx], -1)[None].contiguous()
 grid = grid + 0.01 * torch.sin(7 * grid.flip(-1))
+if os.environ.get("GRID") == "affine3":      # bench.py's stand-alone leg: rotations about all three axes, shear, scale
+    from keymorph_amd import synthetic
+    from keymorph_amd.transformations import AffineTransform
+    grid = AffineTransform(matrix=synthetic.random_affine_matrix(3, dev), dim=3).get_flow_field((1, 1, S, S, S)).contiguous()
 out = torch.empty_like(x); loss = torch.empty(1, device=dev); dg = torch.empty_like(grid)
 ws = torch.empty(int(lib.kmh_reduce_ws_bytes()), dtype=torch.uint8, device=dev)
 st = torch.cuda.current_stream().cuda_stream
