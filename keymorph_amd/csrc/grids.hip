@@ -111,7 +111,9 @@ __global__ __launch_bounds__(192) void affine_grid_bwd_final(const double* __res
 // ROWQ (implicit grid with W % VPT == 0): the lane's VPT voxels are consecutive in x, so (cz - z)^2 + (cy - y)^2 + 1e-6 --
 // the inner two links of tps_d2's fma chain -- is ONE scalar per keypoint instead of VPT/2 packed evaluations: 4 plain
 // VALU replace 8 packed ones of the 22 per keypoint and voxel quad, bit-identical results (the chain's order is kept).
-template <bool EXPLICIT_POINTS, bool ROWQ = false>
+// TV voxels per lane: 8 on the implicit grid when W % 8 == 0 (the per-keypoint work -- two LDS reads, the row constant -- is
+// shared by twice the voxels), else VPT
+template <bool EXPLICIT_POINTS, bool ROWQ = false, int TV = VPT>
 __global__ __launch_bounds__(TPB) void tps_eval_fwd_kernel(const float* __restrict__ theta,
                                                            const float* __restrict__ ctrl,
                                                            const float* __restrict__ pts,
@@ -129,13 +131,13 @@ __global__ __launch_bounds__(TPB) void tps_eval_fwd_kernel(const float* __restri
     sw[t] = make_float4(th[t * 3] * hl, th[t * 3 + 1] * hl, th[t * 3 + 2] * hl, 0.f);
   }
   __syncthreads();
-  const long long v0 = ((long long)blockIdx.x * TPB + threadIdx.x) * VPT;
+  const long long v0 = ((long long)blockIdx.x * TPB + threadIdx.x) * TV;
   if (v0 >= npts) return;
   const float* a = th + (long long)T * 3;  // rows: 1, z, y, x ; cols: (z, y, x) outputs
-  float pz[VPT], py[VPT], px[VPT], oz[VPT], oy[VPT], ox[VPT];
+  float pz[TV], py[TV], px[TV], oz[TV], oy[TV], ox[TV];
   const float sz = lin_step(D), sy = lin_step(H), sx = lin_step(W);
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) {
+  for (int i = 0; i < TV; ++i) {
     long long v = v0 + i;
     if (v >= npts) v = npts - 1;
     if (EXPLICIT_POINTS) {
@@ -147,10 +149,10 @@ __global__ __launch_bounds__(TPB) void tps_eval_fwd_kernel(const float* __restri
     }
   }
   // packed fp32 (v_pk_*_f32): two voxels per instruction; the transcendentals stay scalar
-  static_assert(VPT % 2 == 0, "voxel pairs");
-  kmh_f2 qz[VPT / 2], qy[VPT / 2], qx[VPT / 2], az2[VPT / 2], ay2[VPT / 2], ax2[VPT / 2];
+  static_assert(TV % 2 == 0, "voxel pairs");
+  kmh_f2 qz[TV / 2], qy[TV / 2], qx[TV / 2], az2[TV / 2], ay2[TV / 2], ax2[TV / 2];
 #pragma unroll
-  for (int h = 0; h < VPT / 2; ++h) {
+  for (int h = 0; h < TV / 2; ++h) {
     qz[h] = kmh_f2{pz[2 * h], pz[2 * h + 1]}; qy[h] = kmh_f2{py[2 * h], py[2 * h + 1]}; qx[h] = kmh_f2{px[2 * h], px[2 * h + 1]};
     az2[h] = ay2[h] = ax2[h] = kmh_f2{0.f, 0.f};
   }
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(TPB) void tps_eval_fwd_kernel(const float* __restri
       const float zy = fmaf(dys, dys, fmaf(dzs, dzs, 1e-6f));      // tps_d2's chain up to its last link
       const kmh_f2 zy2 = {zy, zy};
 #pragma unroll
-      for (int h = 0; h < VPT / 2; ++h) {
+      for (int h = 0; h < TV / 2; ++h) {
         const kmh_f2 dx = c.z - qx[h];
         const kmh_f2 u = tps_u2_from_d2(__builtin_elementwise_fma(dx, dx, zy2));
         az2[h] += u * w.x; ay2[h] += u * w.y; ax2[h] += u * w.z;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(TPB) void tps_eval_fwd_kernel(const float* __restri
       const float4 c = sc[t];
       const float4 w = sw[t];
 #pragma unroll
-      for (int h = 0; h < VPT / 2; ++h) {
+      for (int h = 0; h < TV / 2; ++h) {
         const kmh_f2 dz = c.x - qz[h], dy = c.y - qy[h], dx = c.z - qx[h];
         const kmh_f2 u = tps_u2_from_d2(tps_d2(dz, dy, dx));
         az2[h] += u * w.x; ay2[h] += u * w.y; ax2[h] += u * w.z;
@@ -184,13 +186,13 @@ __global__ __launch_bounds__(TPB) void tps_eval_fwd_kernel(const float* __restri
     }
   }
 #pragma unroll
-  for (int h = 0; h < VPT / 2; ++h) {
+  for (int h = 0; h < TV / 2; ++h) {
     oz[2 * h] = az2[h].x; oz[2 * h + 1] = az2[h].y; oy[2 * h] = ay2[h].x; oy[2 * h + 1] = ay2[h].y;
     ox[2 * h] = ax2[h].x; ox[2 * h + 1] = ax2[h].y;
   }
-  float r[VPT * 3];
+  float r[TV * 3];
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) {
+  for (int i = 0; i < TV; ++i) {
     const float az = a[0] + a[3] * pz[i] + a[6] * py[i] + a[9] * px[i];
     const float ay = a[1] + a[4] * pz[i] + a[7] * py[i] + a[10] * px[i];
     const float ax = a[2] + a[5] * pz[i] + a[8] * py[i] + a[11] * px[i];
@@ -201,13 +203,12 @@ __global__ __launch_bounds__(TPB) void tps_eval_fwd_kernel(const float* __restri
     }
   }
   float* o = out + ((long long)n * npts + v0) * 3;
-  if (v0 + VPT <= npts && (npts & 3) == 0) {
+  if (v0 + TV <= npts && (npts & 3) == 0) {
     float4* o4 = reinterpret_cast<float4*>(o);
-    o4[0] = make_float4(r[0], r[1], r[2], r[3]);
-    o4[1] = make_float4(r[4], r[5], r[6], r[7]);
-    o4[2] = make_float4(r[8], r[9], r[10], r[11]);
+#pragma unroll
+    for (int k = 0; k < TV * 3 / 4; ++k) o4[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
   } else {
-    for (int i = 0; i < VPT; ++i)
+    for (int i = 0; i < TV; ++i)
       if (v0 + i < npts) { o[i * 3] = r[i * 3]; o[i * 3 + 1] = r[i * 3 + 1]; o[i * 3 + 2] = r[i * 3 + 2]; }
   }
 }
@@ -501,8 +502,12 @@ KMH_API int kmh_tps_grid_fwd(const float* theta, const float* ctrl, float* out, 
   const size_t lds = (size_t)T * 2 * sizeof(float4);
   if (lds > 64 * 1024) return -22;
   static const bool no_rowq = getenv("KMH_TPS_NO_ROWQ") != nullptr;       // A/B switch (tools/prof_tps.py)
+  static const int tv = getenv("KMH_TPS_TV") ? atoi(getenv("KMH_TPS_TV")) : 8;
   const dim3 g(ceil_div(nvox, (long long)TPB * VPT), N);
-  if (W % VPT == 0 && !no_rowq)
+  if (W % 8 == 0 && !no_rowq && tv == 8)
+    tps_eval_fwd_kernel<false, true, 8><<<dim3(ceil_div(nvox, (long long)TPB * 8), N), TPB, lds, (hipStream_t)stream>>>(
+        theta, ctrl, nullptr, out, T, D, H, W, nvox);
+  else if (W % VPT == 0 && !no_rowq)
     tps_eval_fwd_kernel<false, true><<<g, TPB, lds, (hipStream_t)stream>>>(theta, ctrl, nullptr, out, T, D, H, W, nvox);
   else
     tps_eval_fwd_kernel<false, false><<<g, TPB, lds, (hipStream_t)stream>>>(theta, ctrl, nullptr, out, T, D, H, W, nvox);
