@@ -302,6 +302,34 @@ def test_groupwise_8x256(world, tmp_path):
         else:
             grid = np.load(os.path.join(tmp_path, files[2]), mmap_mode="r")
             assert grid.shape == (1, SIZE, SIZE, SIZE, 3) and bool(np.isfinite(grid[0, ::8, ::8, ::8]).all())
+    # tps_0 against the oracle where a comparison means something: ONE iteration (the mean is then the plain mean of the
+    # keypoints, the same numbers on both sides; five chaotic lambda = 0 iterations amplify 1e-7 into anything).  The statement is
+    # SURVEY F7's: |ours - fp64| <= max(1e-4, 1.25 |reference fp32 - fp64|), for the aligned points of the iteration
+    # (model.py:331-444: subject -> mean) and for the final map's grid (model.py:453-510: mean -> subject) at 4096 lattice points.
+    with torch.no_grad():
+        one = km.groupwise_register(stack, transform_type=["tps_0"], device=dev, num_iters=1, save_results_to_disk=False)["tps_0"]
+    p32 = pts.cpu()
+    mean32 = p32.mean(dim=0, keepdim=True)
+    p64, mean64 = p32.double(), p32.double().mean(dim=0, keepdim=True)
+    z32, z64 = torch.zeros(1), torch.zeros(1, dtype=torch.float64)
+    g32 = O.base_grid((SIZE, SIZE, SIZE))[idx[0], idx[1], idx[2]].reshape(1, -1, 3)
+    worst = {"points": (0.0, 0.0), "grid": (0.0, 0.0)}
+    for i in range(n_sub):
+        a32 = O.tps_transform_points(O.tps_fit(p32[i:i + 1], mean32, z32), p32[i:i + 1], p32[i:i + 1])[0].double()
+        a64 = O.tps_transform_points(O.tps_fit(p64[i:i + 1], mean64, z64), p64[i:i + 1], p64[i:i + 1])[0]
+        ours = one["grouppoints_a"][i].cpu().double()
+        e_ours, e_ref = float((ours - a64).abs().max()), float((a32 - a64).abs().max())
+        worst["points"] = max(worst["points"], (e_ours, e_ref))
+        assert e_ours <= max(1e-4, 1.25 * e_ref), ("tps_0 aligned points", i, e_ours, e_ref)
+        if i in (0, 5):
+            w32 = O.tps_transform_points(O.tps_fit(mean32, p32[i:i + 1], z32), mean32, g32).flip(-1)[0].double()
+            w64 = O.tps_transform_points(O.tps_fit(mean64, p64[i:i + 1], z64), mean64, g32.double()).flip(-1)[0]
+            og = one["groupgrids"][i][idx[0].to(dev), idx[1].to(dev), idx[2].to(dev)].cpu().double()
+            e_ours, e_ref = float((og - w64).abs().max()), float((w32 - w64).abs().max())
+            worst["grid"] = max(worst["grid"], (e_ours, e_ref))
+            assert e_ours <= max(1e-4, 1.25 * e_ref), ("tps_0 final grid", i, e_ours, e_ref)
+    print(f"groupwise 8x256 tps_0, one iteration: |ours - fp64| / |reference fp32 - fp64|: aligned points "
+          f"{worst['points'][0]:.2e} / {worst['points'][1]:.2e}, grid samples {worst['grid'][0]:.2e} / {worst['grid'][1]:.2e}")
     # a group of identical subjects: identical keypoints = their own mean, every map the identity
     from keymorph_amd import ops
     with torch.no_grad():
