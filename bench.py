@@ -205,7 +205,10 @@ def roofline(mode, conv_tf):
             "achieved": conv_tf, "peak": peak, "unit": "TFLOP/s", "frac": conv_tf / peak,
             "mfma_util": conv_tf * mult / MFMA_BF16_PEAK_TFLOPS,
             "vs_fp32_mfma_peak": conv_tf / MFMA_FP32_PEAK_TFLOPS, "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": src}
+            "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": src,
+            "clock_note": "peak is the guide's 2.5 PFLOP/s at 2.4 GHz; these launches sustain 1.79-1.87 GHz under the power "
+                          "cap (GRBM_GUI_ACTIVE / duration, profiles/r4k_effective_clock.txt), i.e. frac x 1.29 of the peak "
+                          "at the sustained clock"}
 
 
 def cpu_baseline(threads, seconds):

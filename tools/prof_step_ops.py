@@ -1,0 +1,28 @@
+"""Which ATen ops run inside one headline training step, and what they cost on the GPU (torch.profiler, grouped by op and
+input shapes): the housekeeping around the C-ABI launches.  usage: python tools/prof_step_ops.py [size] [keypoints]"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from keymorph_amd import parallel, synthetic
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+dev = torch.device("cuda:0")
+model = bench.build_model(K, dev)
+flat = parallel.FlatParams(model.parameters())
+opt = parallel.FusedAdam(flat, lr=3e-6)
+pairs = [synthetic.make_pair(size, s, dev) for s in (0, 1)]
+img_f, img_m = torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs])
+for _ in range(2):
+    bench.train_step(model, flat, opt, img_f, img_m, "tps_0")
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
+    for _ in range(2):
+        bench.train_step(model, flat, opt, img_f, img_m, "tps_0")
+    torch.cuda.synchronize()
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.device_time_total > 0]
+rows.sort(key=lambda e: -e.device_time_total)
+tot = sum(e.self_device_time_total for e in rows)
+print(f"aten ops with GPU time over 2 steps: {tot / 1e3:.2f} ms self device time in {sum(e.count for e in rows)} calls")
+for e in rows[:45]:
+    print(f"{e.self_device_time_total / 2e3:8.3f} ms/step  {e.count // 2:4d}/step  {e.key:28s} {str(e.input_shapes)[:110]}")
