@@ -56,6 +56,19 @@ def _needs_range_scales() -> bool:
     return _TERMS.get(CONV_MODE, 0) == 2
 
 
+_CONSTS = {}
+
+
+def _const(device, *values) -> Tensor:
+    """a small constant tensor on `device`, created once: torch.tensor(list, device=cuda) is a blocking host-to-device copy,
+    i.e. a point where the host waits for the stream to drain (seven of them per training step before round 4)"""
+    key = (str(device), values)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(values, dtype=torch.float32, device=device)
+    return t
+
+
 def absmax_scale(x: Tensor, min_abs: float = 0.0) -> Tensor:
     """device float[2] = {S, 1/S}: the power-of-two range scale of one operand tensor of an f16x3 convolution."""
     lib = _lib.load()
@@ -309,7 +322,7 @@ def conv3_up2_dgrad(dz: Tensor, weight: Tensor, Cs: int, Cl: int, dscale: Option
     terms = _TERMS[CONV_MODE]
     wsu = None
     if terms == 2:
-        wsu = absmax_scale(weight[:, Cs:].contiguous()) * torch.tensor([0.125, 8.0], device=dz.device)
+        wsu = absmax_scale(weight[:, Cs:].contiguous()) * _const(dz.device, 0.125, 8.0)
         if dscale is None:
             dscale = absmax_scale(dz)
     pk = torch.empty(int(lib.kmh_conv3d_up2_dgrad_pack_bytes(Cout, Cl, terms)), dtype=torch.uint8, device=dz.device)
@@ -540,7 +553,7 @@ def _up2_forward(skip, low, scale, shift, ascale, weight, N, D, H, W, Cs, Cl, Co
     pk_s = pack_weight(weight[:, :Cs].contiguous(), False)
     wsu = None
     if terms == 2:   # room for the sum of 8 taps
-        wsu = absmax_scale(weight[:, Cs:].contiguous()) * torch.tensor([0.125, 8.0], device=dev)
+        wsu = absmax_scale(weight[:, Cs:].contiguous()) * _const(dev, 0.125, 8.0)
     pku = torch.empty(int(lib.kmh_conv3d_up2_pack_bytes(Cout, Cl, terms)), dtype=torch.uint8, device=dev)
     check(lib.kmh_conv3d_up2_pack_weight(_p(weight), _p(pku), Cout, Cs + Cl, Cs, Cl, terms, _p(wsu), _stream()),
           "kmh_conv3d_up2_pack_weight")
@@ -630,7 +643,7 @@ class _UpCatConvGCR(torch.autograd.Function):
             terms = _TERMS[CONV_MODE]
             dwn = _f32((N, Cl, 27, Cout), dy.device)
             gws = workspace(int(lib.kmh_up2_wgrad_gemm_ws_bytes(N, Vl, Cl, 27 * Cout)), dy.device, "wgrad")
-            bsc = (dscale * torch.tensor([0.125, 8.0], device=dy.device)) if terms == 2 else None   # sums of 8
+            bsc = (dscale * _const(dy.device, 0.125, 8.0)) if terms == 2 else None   # sums of 8
             if _lib.profiler.enabled:
                 _lib.profiler.meta = {"flops": 2.0 * 27 * Cl * Cout * N * Vl, "shape": (N, Vl, Cl, 27 * Cout)}
             # (the raw low tensor: GroupNorm's affine is applied while the product stages it)
@@ -673,7 +686,7 @@ class _UpCatConvGCR(torch.autograd.Function):
                                     _p(flag), _stream()), "kmh_gn_bwd_coeffs")
         # dx = mask * (c1 dxn + c2 x + c3); summed over 8 children for the upsampled half: c1 S + 8 c2 x_low + 8 c3
         c_s = c123[:, :Cs].contiguous()
-        c_l = (c123[:, Cs:] * torch.tensor([1.0, 8.0, 8.0], device=dy.device)).contiguous()
+        c_l = (c123[:, Cs:] * _const(dy.device, 1.0, 8.0, 8.0)).contiguous()
         want = _needs_range_scales()
         sc_s = torch.zeros(2, dtype=torch.float32, device=dy.device) if want else None
         sc_l = torch.zeros(2, dtype=torch.float32, device=dy.device) if want else None

@@ -90,6 +90,18 @@ class KeyMorph(nn.Module):
             return torch.tensor(loguniform.rvs(1e-6, self.max_rand_tps_lmbda, size=num_samples))
         return torch.tensor(tps_lmbda).repeat(num_samples)
 
+    def _tps_lmbda_on(self, num_samples, tps_lmbda, device):
+        """_convert_tps_lmbda(...).to(device).float(); a FIXED lambda is created on the device once per (value, count) -- the
+        host-to-device copy of a fresh CPU tensor is a blocking point in every step otherwise"""
+        if isinstance(tps_lmbda, str):
+            return self._convert_tps_lmbda(num_samples, tps_lmbda).to(device).float()
+        cache = self.__dict__.setdefault("_lmbda_cache", {})
+        key = (float(tps_lmbda), int(num_samples), str(device))
+        t = cache.get(key)
+        if t is None:
+            t = cache[key] = self._convert_tps_lmbda(num_samples, tps_lmbda).to(device).float()
+        return t
+
     @staticmethod
     def is_supported_transform_type(s):
         return s in ["affine", "rigid"] or bool(re.match(r"^tps_.*$", s))
@@ -161,7 +173,7 @@ class KeyMorph(nn.Module):
             n = len(img_f)
             ctrl, tgt, lam = [], [], []
             for t in tps_types:
-                lm = self._convert_tps_lmbda(n, str_or_float(t[4:])).to(img_f.device).float()
+                lm = self._tps_lmbda_on(n, str_or_float(t[4:]), img_f.device)
                 ctrl.append(points_f); tgt.append(points_m); lam.append(lm)             # inverse map: fixed -> moving
                 if return_aligned_points:
                     ctrl.append(points_m); tgt.append(points_f); lam.append(lm)         # forward map: moving -> fixed
@@ -177,7 +189,7 @@ class KeyMorph(nn.Module):
             start_time = time.time()
             if align_type_str.startswith("tps"):
                 align_type = "tps"
-                tps_lmbda = self._convert_tps_lmbda(len(img_f), str_or_float(align_type_str[4:])).to(img_f.device)
+                tps_lmbda = self._tps_lmbda_on(len(img_f), str_or_float(align_type_str[4:]), img_f.device)
             else:
                 align_type = align_type_str
                 tps_lmbda = None
@@ -272,7 +284,7 @@ class KeyMorph(nn.Module):
             start_time = time.time()
             if align_type_str.startswith("tps"):
                 align_type = "tps"
-                tps_lmbda = self._convert_tps_lmbda(1, str_or_float(align_type_str[4:])).to(device)
+                tps_lmbda = self._tps_lmbda_on(1, str_or_float(align_type_str[4:]), device)
             else:
                 align_type, tps_lmbda = align_type_str, None
 
