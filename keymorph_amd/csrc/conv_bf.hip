@@ -871,6 +871,384 @@ __global__ __launch_bounds__(G_TPB, 2) void conv3_fwd_g_kernel(
   }
 }
 
+
+// =============================================================================================
+// conv3_fwd_s_kernel -- ONE wave per SIMD (round 4).  What the cycle stamps of conv3_fwd_g_kernel say: a chunk is
+// ~31.3k cycles = tap-pair steps 26.0k (two waves per SIMD share the matrix pipe: 77 cycles per MFMA and wave, 83 % of the
+// pipe) + a conversion phase of 4.2k + two barriers, and with two waves per SIMD nothing can be moved into the MFMA shadow:
+// their issue streams are zero-sum (MI355X_MICROARCH.md "Two waves per SIMD", item 3; measured here too: DESIGN.md section 8).
+// A SINGLE wave per SIMD with the whole register file does hide up to ~5 single-issue instructions per MFMA gap (same
+// guide, constants table).  So: 256 threads = 4 waves, wave = one plane of the 32 x 8 x 4 brick = 8 rows x NT cout tiles
+// (256 accumulator registers for NT = 2, every B fragment reused by 8 rows), and per step the wave's stream is
+//   wait for this step's B fragments | two LDS-DMA pieces of the NEXT stage's halo (steps 0-7) | the A fragments of the
+//   NEXT step into a second register set | 48 MFMAs with, from step 8 on, the in-place conversion of the next stage's
+//   voxels (the lane's own: it fetched both 16-byte halves itself) scheduled between them | the B loads of step s + 4.
+// Two stage buffers of 2 x 2048 16-byte slots (fp32 halves in, fp16 hi / lo planes out, in place), ONE barrier per stage.
+// Bit-identical to conv3_fwd_g_kernel / conv3_fwd_bf_kernel: per accumulator the three products keep their order (the loop
+// runs term-major over the 16 accumulators, so back-to-back MFMAs never hit the same one).
+constexpr int S_TPB = 256, S_MR = 8;
+constexpr int S_PLANE = 2048;                                         // 16-byte slots per plane of a stage buffer (>= GPL)
+constexpr int S_NLD = 2 * S_PLANE / S_TPB;                            // 16 LDS-DMA instructions per thread and chunk
+constexpr int S_NCV = S_PLANE / S_TPB;                                // 8 voxels converted per thread and chunk
+constexpr int S_BUF_BYTES = 2 * S_PLANE * 16;                         // 65 536
+constexpr int S_OFF_BYTES = S_NLD * S_TPB * 4;                        // 16 384
+constexpr int S_COEF = 1024;                                          // channels of one sample's (scale, shift) table
+constexpr int S_LDS_BYTES = 2 * S_BUF_BYTES + S_OFF_BYTES + 2 * S_COEF * 4;      // 155 648
+static_assert(GPL <= S_PLANE && GTZ == 4 && GTY == S_MR, "wave = plane, 8 rows");
+#ifndef KMH_S_VPM
+#define KMH_S_VPM 3
+#endif
+#ifndef KMH_S_CONV0
+#define KMH_S_CONV0 8
+#endif
+
+template <int NT>
+__global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    const bf16x8* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int D, int H, int W, int Cin,
+    int Cout, int CoutP, int relu_in, int relu_out, int tiles_x, int tiles_y, int tiles_z, int tiles_zp,
+    const float* __restrict__ ascale, const float* __restrict__ wscale, double* __restrict__ stats_partial,
+    int in_blocked, const float* __restrict__ addend, int total_items, int N, long long* __restrict__ trace) {
+  constexpr int TERMS = 2, MR = S_MR, NST = NSTEP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  int* sOff = reinterpret_cast<int*>(gsm + 2 * S_BUF_BYTES);
+  float* sCoef = reinterpret_cast<float*>(gsm + 2 * S_BUF_BYTES + S_OFF_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int ncog = (Cout + 32 * NT - 1) / (32 * NT);
+  const int tyz = (tiles_y + 7) >> 3;
+  struct Item { int n, cog, bx, by, bz; };
+  const int total_all = N * total_items;
+  auto decode = [&](int vb, Item& it) -> bool {      // the work list of conv3_fwd_g_kernel
+    const int gitem = xcd_remap(vb, total_all);
+    it.n = gitem / total_items;
+    const int item = gitem - it.n * total_items;
+    it.cog = item % ncog;
+    const int brick = item / ncog;
+    const int lz8 = brick & 7, ly8 = (brick >> 3) & 7, patch = brick >> 6;
+    const int pyi = patch % tyz, rest = patch / tyz;
+    const int pzi = rest % tiles_zp;
+    it.bx = rest / tiles_zp; it.by = pyi * 8 + ly8; it.bz = pzi * 8 + lz8;
+    return it.by < tiles_y && it.bz < tiles_z;
+  };
+  auto next_item = [&](int& vb, Item& it) -> bool {
+    for (vb += gridDim.x; vb < total_all; vb += gridDim.x)
+      if (decode(vb, it)) return true;
+    return false;
+  };
+  int vb = (int)blockIdx.x - (int)gridDim.x;
+  Item cur, nxt;
+  if (!next_item(vb, cur)) return;
+
+  const float sA = ascale ? ascale[0] : 1.f;
+  const float desc = (ascale ? ascale[1] : 1.f) * (wscale ? wscale[1] : 1.f);
+  const int nchunk = Cin / KC;
+  const int vrow = (wv * GHY) * HX + li;                  // wave = output plane wv, rows 0..7
+  const long long vox = (long long)D * H * W;
+  const long long chunk_stride = in_blocked ? vox * KC : KC;
+  auto sample_base = [&](int n) { return in_blocked ? x + (long long)n * nchunk * vox * KC : x + (long long)n * vox * Cin; };
+
+  // LDS-DMA descriptors of a brick: 16-byte slot e = r * 256 + tid holds half (r >> 3) of halo voxel (r & 7) * 256 + tid
+  auto fill_offsets = [&](const Item& it) {
+    const int x0 = it.bx * TX, y0 = it.by * GTY, z0 = it.bz * GTZ;
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+#pragma unroll
+    for (int r = 0; r < S_NLD; ++r) {
+      const int e = r * S_TPB + t_, v0_ = (r & 7) * S_TPB + t_, v = v0_ < GPL ? v0_ : GPL - 1;
+      const int lx = v % HX, ly = (v / HX) % GHY, lz = v / (HX * GHY);
+      int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - 1;
+      gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+      gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+      gz = gz < 0 ? 0 : (gz > D - 1 ? D - 1 : gz);
+      sOff[e] = ((gz * H + gy) * W + gx) * (in_blocked ? KC : Cin) + 4 * (r >> 3);      // read back by this thread only
+    }
+  };
+  auto inside_bits = [&](const Item& it) -> unsigned {     // bit i: voxel tid + 256 i of the halo is inside the volume
+    const int x0 = it.bx * TX, y0 = it.by * GTY, z0 = it.bz * GTZ;
+    unsigned bits = 0;
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+#pragma unroll
+    for (int i = 0; i < S_NCV; ++i) {
+      const int v = t_ + i * S_TPB;
+      const int lx = v % HX, ly = (v / HX) % GHY, lz = v / (HX * GHY);
+      const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - 1;
+      const bool in = (v < GPL) && ((unsigned)gx < (unsigned)W) && ((unsigned)gy < (unsigned)H) && ((unsigned)gz < (unsigned)D);
+      bits |= (in ? 1u : 0u) << i;
+    }
+    return bits;
+  };
+  // pieces j and 8 + j of the wave's 16: the two halves of the lane's voxel j (source offsets read from the table one step
+  // ahead: a ds_read -> wait -> DMA chain at the head of a step stalls the whole in-order stream)
+  auto dma_pair = [&](int n, int ch, int pb, int j, int off0, int off1) {
+    const float* base = sample_base(n) + ch * chunk_stride;
+    float4* dst = reinterpret_cast<float4*>(gsm + pb * S_BUF_BYTES);
+    __builtin_amdgcn_global_load_lds((kmh_glb_ptr)(base + off0), (kmh_lds_ptr)(dst + j * S_TPB + wv * 64), 16, 0, G_AUX);
+    __builtin_amdgcn_global_load_lds((kmh_glb_ptr)(base + off1), (kmh_lds_ptr)(dst + (8 + j) * S_TPB + wv * 64), 16, 0, G_AUX);
+  };
+  int coef_n = -1;
+  auto fill_coef = [&](int n_) {                      // (the caller's barrier publishes it)
+    for (int e = tid; e < Cin; e += S_TPB) {
+      sCoef[e] = (scale ? scale[n_ * Cin + e] : 1.f) * sA;
+      sCoef[S_COEF + e] = (scale ? shift[n_ * Cin + e] : 0.f) * sA;
+    }
+    coef_n = n_;
+  };
+  // in-place conversion of the lane's voxel i of stage buffer pb (sample coef_n): branch-free, scheduled INTO a step's MFMA
+  // block; slots past the halo hold a clamped voxel's data and convert to zeros
+  auto convert1 = [&](int ch, unsigned bits, int pb, int i) {
+    const float4 a0 = *reinterpret_cast<const float4*>(sCoef + ch * KC), a1 = *reinterpret_cast<const float4*>(sCoef + ch * KC + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(sCoef + S_COEF + ch * KC), b1 = *reinterpret_cast<const float4*>(sCoef + S_COEF + ch * KC + 4);
+    const float csc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float csh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float4* B4 = reinterpret_cast<float4*>(gsm + pb * S_BUF_BYTES);
+    bf16x8* B8 = reinterpret_cast<bf16x8*>(gsm + pb * S_BUF_BYTES);
+    const int v = tid + i * S_TPB;
+    const float4 r0 = B4[v], r1 = B4[S_PLANE + v];
+    const float raw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    const bool in = (bits >> i) & 1u;
+    float val[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = raw[j] * csc[j] + csh[j];
+      t = relu_in ? fmaxf(t, 0.f) : t;
+      val[j] = in ? t : 0.f;                             // zero padding AFTER the normalisation
+    }
+    bf16x8 parts[TERMS];
+    split8<TERMS>(val, parts);
+#pragma unroll
+    for (int t = 0; t < TERMS; ++t) B8[t * S_PLANE + v] = parts[t];
+  };
+
+  // B fragments straight from L2 through a register ring BD steps deep (as conv3_fwd_g_kernel: hand-counted waits)
+  constexpr int BD = 4;
+  constexpr int BL = 2 * NT;
+  const long long step_stride = 2ll * CoutP, term_stride = (long long)NST * step_stride;
+  bf16x8 bq[BD][NT][TERMS];
+  long long o0 = 0;
+  auto b_issue = [&](int slot) {
+    const bf16x8* p0 = wp + o0;
+    const bf16x8* p1 = p0 + term_stride;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[slot][0][0]) : "v"(p0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[slot][0][1]) : "v"(p1) : "memory");
+    if (NT == 2) {
+      asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(bq[slot][NT - 1][0]) : "v"(p0) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(bq[slot][NT - 1][1]) : "v"(p1) : "memory");
+    }
+    o0 += step_stride;
+  };
+  auto a_offset = [&](int s) -> int {                    // LDS slot offset of this lane's A fragment of step s, row 0
+    constexpr int last_tap = 26;
+    const int tapA = 2 * s, tapB = (2 * s + 1 > last_tap) ? last_tap : 2 * s + 1;      // padded half-step: zero weights
+    const int offA = ((tapA / 9) * GHY + (tapA / 3) % 3) * HX + tapA % 3;
+    const int offB = ((tapB / 9) * GHY + (tapB / 3) % 3) * HX + tapB % 3;
+    return lh ? offB : offA;
+  };
+
+  int tr_n = 0;                                            // KMH_G_TRACE: cycle stamps of workgroup 0, wave 0
+  auto stamp = [&]() {
+    if (trace && blockIdx.x == 0 && tid == 0 && tr_n < 240) trace[tr_n++] = __builtin_readcyclecounter();
+  };
+  // prologue: the first stage's halo, fetched and converted with nothing to hide behind
+  fill_offsets(cur);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dma_pair(cur.n, 0, 0, j, sOff[j * S_TPB + tid], sOff[(8 + j) * S_TPB + tid]);
+  unsigned cv_in = inside_bits(cur);
+  fill_coef(cur.n);
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < S_NCV; ++i) convert1(0, cv_in, 0, i);
+  int pb = 0;                                              // stage buffer holding the CURRENT stage's fragment images
+  constexpr int CONV0 = KMH_S_CONV0;                       // first conversion step (every DMA piece was issued by step 7)
+  static_assert(CONV0 >= 8 && CONV0 + 6 <= NST, "8 voxels over the steps CONV0 .. NST - 1");
+  for (;;) {
+    const bool more = next_item(vb, nxt);
+    const int co0 = cur.cog * (32 * NT);
+    const int n = cur.n;
+    const int boff = lh * CoutP + co0 + li;
+    f32x16 acc[MR][NT];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+      // stage top: this wave's conversion writes are out; after the barrier everybody's are -- and every wave is done with
+      // the MFMAs (and the epilogue tiles) of the previous stage: the other buffer may be overwritten by the next DMA
+      stamp();                                             // stage top
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stamp();                                             // barrier passed
+      const bf16x8* sIn = reinterpret_cast<const bf16x8*>(gsm + pb * S_BUF_BYTES);      // [TERMS][S_PLANE]
+      const bool last_ch = ch + 1 == nchunk;
+      const bool have_next = !last_ch || more;
+      if (last_ch && more) fill_offsets(nxt);
+      const int nn = (last_ch && more) ? nxt.n : n, nch = last_ch ? 0 : ch + 1;      // (no next stage: any valid pair)
+      const unsigned cv_next = last_ch ? (more ? inside_bits(nxt) : 0u) : cv_in;
+      if (nn != coef_n) {                                  // uniform, rare: the work list moves on to another sample
+        fill_coef(nn);
+        __syncthreads();
+      }
+      o0 = (long long)ch * TERMS * term_stride + boff;
+#pragma unroll
+      for (int d = 0; d < BD; ++d) b_issue(d);
+      int vr = vrow;
+      asm volatile("" : "+v"(vr));
+      int dof0 = sOff[tid], dof1 = sOff[8 * S_TPB + tid];  // the next DMA pair's source offsets
+      bf16x8 a[2][MR][TERMS];                              // this step's A fragments and the next step's
+      {
+        const int ab = vr + a_offset(0);
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int q = 0; q < TERMS; ++q) a[0][m][q] = sIn[q * S_PLANE + ab + m * HX];
+      }
+#pragma unroll
+      for (int s = 0; s < NST; ++s) {
+        {   // this step's B fragments: leave only the B loads issued after them in flight (step CONV0: + every DMA piece)
+          const int ahead = (s + BD - 1 < NST - 1 ? s + BD - 1 : NST - 1) - s;      // steps already issued beyond s
+          switch (s == CONV0 ? 0 : ahead * BL) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          }
+        }
+        // (after the wait: the pieces issued here are the youngest entries of the queue at the next step's wait, which is
+        // then merely stricter -- and a step is ~1.5k cycles, several times a DMA's flight)
+        if (s < 8 && have_next) dma_pair(nn, nch, pb ^ 1, s, dof0, dof1);
+        if (s < 7) { dof0 = sOff[(s + 1) * S_TPB + tid]; dof1 = sOff[(9 + s) * S_TPB + tid]; }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < NST) {
+          const int ab = vr + a_offset(s + 1);
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int q = 0; q < TERMS; ++q) a[(s + 1) & 1][m][q] = sIn[q * S_PLANE + ab + m * HX];
+        }
+        // the next stage's voxels: 2, 2, 1, 1, 1, 1 over the steps CONV0 ..
+        if (s == CONV0) { convert1(nch, cv_next, pb ^ 1, 0); convert1(nch, cv_next, pb ^ 1, 1); }
+        if (s == CONV0 + 1) { convert1(nch, cv_next, pb ^ 1, 2); convert1(nch, cv_next, pb ^ 1, 3); }
+        if (s >= CONV0 + 2 && s < CONV0 + 6) convert1(nch, cv_next, pb ^ 1, s - CONV0 + 2);
+        // term-major over the 8 x NT accumulators: per accumulator the order of conv3_fwd_bf_kernel (smallest terms first)
+#pragma unroll
+        for (int q3 = 0; q3 < 3; ++q3)
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              acc[m][t] = mfma16<TERMS>(a[s & 1][m][q3 == 0 ? 1 : 0], bq[s % BD][t][q3 == 1 ? 1 : 0], acc[m][t]);
+        if (s >= CONV0 && s < CONV0 + 6) {
+          // every LDS read of the block first (the next step's A fragments, the voxels' raw halves, the coefficients): a wait
+          // in the middle of the MFMA stream stalls it
+          __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);
+#pragma unroll
+          for (int k = 0; k < MR * NT * 3; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA ...
+            __builtin_amdgcn_sched_group_barrier(0x002, KMH_S_VPM, 0);     // ... then a few of the conversion's VALU
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + BD < NST) b_issue(s % BD);     // refill the slot just consumed
+        __builtin_amdgcn_sched_barrier(0);
+        if (s == 0 || s == CONV0 - 1 || s == NST - 1) stamp();      // steps 0 / .. CONV0 - 1 / .. NST - 1 done
+      }
+      if (!last_ch) pb ^= 1;                               // (after a brick's last stage the epilogue still uses its buffer)
+    }
+
+    // ---- epilogue of the brick: the wave's rows go through its own 8 KB of the (now idle) stage buffer, row by row, and
+    // are stored 16 bytes per lane (conv3_fwd_g_kernel's epilogue, 8 rows per wave).  (Forming the products transposed --
+    // weights as the A operand, so that four accumulator registers are four channels of one voxel and no LDS transposition is
+    // needed -- was measured: the 32-byte pieces those stores write cost 60-68k cycles per brick against 33k here.)
+    const int x0 = cur.bx * TX, y0 = cur.by * GTY, z0 = cur.bz * GTZ;
+    constexpr int CH = 32 * NT;
+    constexpr int L4 = CH / 4;
+    constexpr int VPI = 64 / L4;
+    const long long sbrick = ((long long)n * tiles_z * tiles_y * tiles_x + ((long long)cur.bz * tiles_y + cur.by) * tiles_x + cur.bx);
+    unsigned char* sEp = gsm + pb * S_BUF_BYTES;
+    float* tile = reinterpret_cast<float*>(sEp) + wv * (32 * CH);
+    const int c4 = lane % L4, vx = lane / L4;
+    const int col = 4 * c4;
+    const int co = co0 + col;
+    const bool co_ok = co < Cout;
+    float4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias && co_ok) bv = *reinterpret_cast<const float4*>(bias + co);
+    float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                           // every wave is done with the fragment images
+    const int gz = z0 + wv;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * CH + 32 * t + li] = acc[m][t][r];
+      const int gy = y0 + m;
+      const bool row_ok = gz < D && gy < H && co_ok;
+      const long long rowoff = ((((long long)n * D + gz) * H + gy) * W) * Cout + co;
+      float4 v4[32 / VPI], ad[32 / VPI];
+#pragma unroll
+      for (int k = 0; k < 32 / VPI; ++k) {
+        const int xx = vx + VPI * k;
+        v4[k] = *reinterpret_cast<const float4*>(tile + xx * CH + col);
+        ad[k] = float4{0.f, 0.f, 0.f, 0.f};
+        if (addend && row_ok && x0 + xx < W) ad[k] = *reinterpret_cast<const float4*>(addend + rowoff + (long long)(x0 + xx) * Cout);
+      }
+#pragma unroll
+      for (int k = 0; k < 32 / VPI; ++k) {
+        const int gx = x0 + vx + VPI * k;
+        if (row_ok && gx < W) {
+          float4 o;
+          o.x = v4[k].x * desc + bv.x + ad[k].x; o.y = v4[k].y * desc + bv.y + ad[k].y;
+          o.z = v4[k].z * desc + bv.z + ad[k].z; o.w = v4[k].w * desc + bv.w + ad[k].w;
+          if (relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+          *reinterpret_cast<float4*>(y + rowoff + (long long)gx * Cout) = o;
+          st1[0] += o.x; st2[0] += o.x * o.x; st1[1] += o.y; st2[1] += o.y * o.y;
+          st1[2] += o.z; st2[2] += o.z * o.z; st1[3] += o.w; st2[3] += o.w * o.w;
+        }
+      }
+    }
+    if (stats_partial) {
+      double d1[4], d2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        d1[j] = (double)st1[j]; d2[j] = (double)st2[j];
+#pragma unroll
+        for (int o = L4; o < 64; o <<= 1) { d1[j] += __shfl_xor(d1[j], o); d2[j] += __shfl_xor(d2[j], o); }
+      }
+      __syncthreads();                                         // the tiles have been read back
+      double* sred = reinterpret_cast<double*>(sEp);           // [wave][CH][2]
+      if (lane < L4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sred[((wv * CH) + col + j) * 2] = d1[j]; sred[((wv * CH) + col + j) * 2 + 1] = d2[j]; }
+      }
+      __syncthreads();
+      if (tid < 2 * CH) {
+        const int k = tid & 1, c = tid >> 1;
+        const int cch = co0 + c;
+        if (cch < Cout) {
+          // (the outputs are bit-identical to conv3_fwd_g_kernel's; these sums group them by plane instead of by
+          // (plane, row half), so they agree with that kernel's to fp32 rounding of the per-lane partial sums, not bit for bit)
+          stats_partial[(sbrick * Cout + cch) * 2 + k] = (sred[(0 * CH + c) * 2 + k] + sred[(1 * CH + c) * 2 + k]) +
+                                                        (sred[(2 * CH + c) * 2 + k] + sred[(3 * CH + c) * 2 + k]);
+        }
+      }
+    }
+    stamp();                                               // epilogue issued
+    if (!more) break;
+    cur = nxt;
+    cv_in = inside_bits(cur);
+    pb ^= 1;
+  }
+}
+
 static inline int cout_pad(int Cout) { return Cout > 64 ? (Cout + 127) & ~127 : (Cout + 63) & ~63; }
 static inline bool use_zpair(int Cout) { return Cout <= 16; }
 
@@ -1629,6 +2007,42 @@ static int launch_fwd_g(const float* x, const float* scale, const float* shift, 
   return KMH_LAUNCH_CHECK();
 }
 
+template <int NT>
+static int launch_fwd_s(const float* x, const float* scale, const float* shift, const bf16x8* wp, const float* bias, float* y,
+                        int N, int D, int H, int W, int Cin, int Cout, int CoutP, int relu_in, int relu_out,
+                        const float* ascale, const float* wscale, double* stats_ws, double* stats_out, hipStream_t s,
+                        int in_blocked, const float* addend) {
+  hipError_t e = hipFuncSetAttribute((const void*)conv3_fwd_s_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     S_LDS_BYTES);
+  if (e != hipSuccess) return (int)e;
+  const int tx = ceil_div(W, TX), ty = ceil_div(H, GTY), tz = ceil_div(D, GTZ);
+  const int typ = ceil_div(ty, 8), tzp = ceil_div(tz, 8);
+  const int total = tx * typ * tzp * 64 * ceil_div(Cout, 32 * NT);      // virtual blocks per sample
+  long long all = (long long)N * total;
+  int wgs = 256;                                          // persistent, one per CU
+  if (wgs > ((all + 7) / 8) * 8) wgs = (int)(((all + 7) / 8) * 8);
+  static long long* trace = nullptr;                       // KMH_G_TRACE=1 (debug): cycle stamps of workgroup 0 to stderr
+  static const bool tracing = getenv("KMH_G_TRACE") != nullptr;
+  if (tracing && !trace) { if (hipMalloc(&trace, 240 * sizeof(long long)) != hipSuccess) trace = nullptr; }
+  if (tracing && trace) (void)hipMemsetAsync(trace, 0, 240 * sizeof(long long), s);
+  conv3_fwd_s_kernel<NT><<<dim3(wgs), S_TPB, S_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in,
+                                                               relu_out, tx, ty, tz, tzp, ascale, wscale,
+                                                               stats_out ? stats_ws : nullptr, in_blocked, addend, total, N,
+                                                               tracing ? trace : nullptr);
+  if (tracing && trace) {
+    long long h[240];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "KMH_G_TRACE fwd_s NT=%d Cin=%d Cout=%d D=%d:", NT, Cin, Cout, D);
+    for (int i = 1; i < 240 && h[i]; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+    fprintf(stderr, "\n");
+  }
+  if (stats_out)
+    kmh_stats::final_kernel<<<dim3(ceil_div(Cout * 2, 256 / kWave), N), 256, 0, s>>>(stats_ws, tx * ty * tz, Cout,
+                                                                                  stats_out);
+  return KMH_LAUNCH_CHECK();
+}
+
 // the LDS-DMA kernel's preconditions: fp16 split, whole 8-channel chunks, no fused mask operand, and enough bricks to
 // give every CU several of them
 // 0: never, 1: when the launch has >= 512 bricks (default), 2: whenever the preconditions hold (parity tests force the
@@ -1736,6 +2150,12 @@ KMH_API int kmh_conv3d_fwd_bf(const float* x, const float* scale, const float* s
   const bool deep = !no_deep && terms == 2 && Cout <= 32 && D >= 16 && (long long)D * H * W >= (1ll << 21);
   if (fwd_g_ok(mask != nullptr, addend != nullptr, N, D, H, W, Cin, Cout, terms)) {
     if (use_zpair(Cout)) return launch_fwd_g<1, true>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
+    // KEYMORPH_FWD_S: the one-wave-per-SIMD kernel for the 64-wide tile (1) and for 16 < Cout <= 32 too (2)
+    static const int fwd_s = getenv("KEYMORPH_FWD_S") ? atoi(getenv("KEYMORPH_FWD_S")) : 0;
+    if (fwd_s && Cin <= S_COEF && !use_zpair(Cout)) {
+      if (Cout > 32) return launch_fwd_s<2>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
+      if (fwd_s >= 2) return launch_fwd_s<1>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
+    }
     if (Cout > 32) return launch_fwd_g<2, false>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
     return launch_fwd_g<1, false>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
   }

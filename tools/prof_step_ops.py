@@ -26,3 +26,9 @@ tot = sum(e.self_device_time_total for e in rows)
 print(f"aten ops with GPU time over 2 steps: {tot / 1e3:.2f} ms self device time in {sum(e.count for e in rows)} calls")
 for e in rows[:45]:
     print(f"{e.self_device_time_total / 2e3:8.3f} ms/step  {e.count // 2:4d}/step  {e.key:28s} {str(e.input_shapes)[:110]}")
+# host-side runtime calls that can stall the launch queue (per step)
+rt = [e for e in prof.key_averages() if e.key.startswith(("hip", "cuda")) and not e.key.startswith(("hipLaunchKernel", "hipExtLaunch", "hipModuleLaunch"))]
+rt.sort(key=lambda e: -e.count)
+print("runtime calls per step (besides kernel launches):")
+for e in rt[:15]:
+    print(f"  {e.count / 2:7.1f}/step  {e.cpu_time_total / 2e3:8.3f} ms/step host  {e.key}")
