@@ -901,6 +901,12 @@ static_assert(GPL <= S_PLANE && GTZ == 4 && GTY == S_MR, "wave = plane, 8 rows")
 #ifndef KMH_S_CONV0
 #define KMH_S_CONV0 8
 #endif
+#ifndef KMH_S_BD
+#define KMH_S_BD 2
+#endif
+#ifndef KMH_S_ADB
+#define KMH_S_ADB 1
+#endif
 
 template <int NT>
 __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
@@ -1022,8 +1028,13 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     for (int t = 0; t < TERMS; ++t) B8[t * S_PLANE + v] = parts[t];
   };
 
-  // B fragments straight from L2 through a register ring BD steps deep (as conv3_fwd_g_kernel: hand-counted waits)
-  constexpr int BD = 4;
+  // B fragments straight from L2 through a register ring (as conv3_fwd_g_kernel: hand-counted waits) that runs THROUGH the
+  // stage boundaries: the last BD steps of a stage load the first BD steps' fragments of the next one (a stage that starts
+  // with an empty ring pays an L2 round trip and then some: cycle stamps, step 0 took 3.3k cycles against 1.8k for the others).
+  // BD = 2 divides the 14 steps, so a step's ring slot is a compile-time constant; one wave per SIMD needs no deeper ring (a
+  // step is ~1.5k cycles, an L2 hit 200-500)
+  constexpr int BD = KMH_S_BD;
+  static_assert(NST % BD == 0, "the ring slot of a step must not depend on the stage");
   constexpr int BL = 2 * NT;
   const long long step_stride = 2ll * CoutP, term_stride = (long long)NST * step_stride;
   bf16x8 bq[BD][NT][TERMS];
@@ -1061,6 +1072,10 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int i = 0; i < S_NCV; ++i) convert1(0, cv_in, 0, i);
+  o0 = lh * CoutP + cur.cog * (32 * NT) + li;             // chunk 0 of the first brick
+#pragma unroll
+  for (int d = 0; d < BD; ++d) b_issue(d);
+  bool first_stage = true;
   int pb = 0;                                              // stage buffer holding the CURRENT stage's fragment images
   constexpr int CONV0 = KMH_S_CONV0;                       // first conversion step (every DMA piece was issued by step 7)
   static_assert(CONV0 >= 8 && CONV0 + 6 <= NST, "8 voxels over the steps CONV0 .. NST - 1");
@@ -1094,13 +1109,13 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
         fill_coef(nn);
         __syncthreads();
       }
-      o0 = (long long)ch * TERMS * term_stride + boff;
-#pragma unroll
-      for (int d = 0; d < BD; ++d) b_issue(d);
+      const int co0n = ((last_ch && more) ? nxt.cog : cur.cog) * (32 * NT);      // the next stage's cout group
+      const bool drain = ch == 0 && !first_stage;          // a brick's first stage: the previous brick's output stores are in
+      first_stage = false;                                 // the queue behind the B loads (counted waits would not see past them)
       int vr = vrow;
       asm volatile("" : "+v"(vr));
       int dof0 = sOff[tid], dof1 = sOff[8 * S_TPB + tid];  // the next DMA pair's source offsets
-      bf16x8 a[2][MR][TERMS];                              // this step's A fragments and the next step's
+      bf16x8 a[KMH_S_ADB ? 2 : 1][MR][TERMS];              // this step's A fragments (and the next step's)
       {
         const int ab = vr + a_offset(0);
 #pragma unroll
@@ -1110,29 +1125,29 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
       }
 #pragma unroll
       for (int s = 0; s < NST; ++s) {
-        {   // this step's B fragments: leave only the B loads issued after them in flight (step CONV0: + every DMA piece)
-          const int ahead = (s + BD - 1 < NST - 1 ? s + BD - 1 : NST - 1) - s;      // steps already issued beyond s
-          switch (s == CONV0 ? 0 : ahead * BL) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-          }
-        }
+        // this step's B fragments: leave only the B loads of the next BD - 1 steps in flight (step CONV0: nothing -- every DMA
+        // piece of the next stage has landed then; step 0 of a brick's first stage: nothing -- see `drain`)
+        if (s == CONV0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (s == 0) { if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * BL) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * BL) : "memory");
         // (after the wait: the pieces issued here are the youngest entries of the queue at the next step's wait, which is
         // then merely stricter -- and a step is ~1.5k cycles, several times a DMA's flight)
         if (s < 8 && have_next) dma_pair(nn, nch, pb ^ 1, s, dof0, dof1);
         if (s < 7) { dof0 = sOff[(s + 1) * S_TPB + tid]; dof1 = sOff[(9 + s) * S_TPB + tid]; }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < NST) {
+        if (KMH_S_ADB && s + 1 < NST) {
           const int ab = vr + a_offset(s + 1);
 #pragma unroll
           for (int m = 0; m < MR; ++m)
 #pragma unroll
             for (int q = 0; q < TERMS; ++q) a[(s + 1) & 1][m][q] = sIn[q * S_PLANE + ab + m * HX];
+        }
+        if (!KMH_S_ADB && s > 0) {                          // single set: read right here, the compiler places the reads
+          const int ab = vr + a_offset(s);
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int q = 0; q < TERMS; ++q) a[0][m][q] = sIn[q * S_PLANE + ab + m * HX];
         }
         // the next stage's voxels: 2, 2, 1, 1, 1, 1 over the steps CONV0 ..
         if (s == CONV0) { convert1(nch, cv_next, pb ^ 1, 0); convert1(nch, cv_next, pb ^ 1, 1); }
@@ -1145,7 +1160,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
           for (int m = 0; m < MR; ++m)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-              acc[m][t] = mfma16<TERMS>(a[s & 1][m][q3 == 0 ? 1 : 0], bq[s % BD][t][q3 == 1 ? 1 : 0], acc[m][t]);
+              acc[m][t] = mfma16<TERMS>(a[KMH_S_ADB ? (s & 1) : 0][m][q3 == 0 ? 1 : 0], bq[s % BD][t][q3 == 1 ? 1 : 0], acc[m][t]);
         if (s >= CONV0 && s < CONV0 + 6) {
           // every LDS read of the block first (the next step's A fragments, the voxels' raw halves, the coefficients): a wait
           // in the middle of the MFMA stream stalls it
@@ -1157,7 +1172,11 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + BD < NST) b_issue(s % BD);     // refill the slot just consumed
+        if (s + BD < NST) b_issue(s % BD);     // refill the slot just consumed: step s + BD of this stage ...
+        else if (have_next) {                  // ... or step s + BD - NST of the next one
+          if (s + BD == NST) o0 = (long long)nch * TERMS * term_stride + lh * CoutP + co0n + li;
+          b_issue(s % BD);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (s == 0 || s == CONV0 - 1 || s == NST - 1) stamp();      // steps 0 / .. CONV0 - 1 / .. NST - 1 done
       }
