@@ -904,6 +904,9 @@ static_assert(GPL <= S_PLANE && GTZ == 4 && GTY == S_MR, "wave = plane, 8 rows")
 #ifndef KMH_S_BD
 #define KMH_S_BD 2
 #endif
+#ifndef KMH_S_LEAD
+#define KMH_S_LEAD 6
+#endif
 #ifndef KMH_S_ADB
 #define KMH_S_ADB 1
 #endif
@@ -986,13 +989,17 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     }
     return bits;
   };
-  // pieces j and 8 + j of the wave's 16: the two halves of the lane's voxel j (source offsets read from the table one step
-  // ahead: a ds_read -> wait -> DMA chain at the head of a step stalls the whole in-order stream)
-  auto dma_pair = [&](int n, int ch, int pb, int j, int off0, int off1) {
+  // the lane's voxel j of the next stage: its two 16-byte halves into a register ring (three voxels in flight: loaded in
+  // step j, converted in step j + 2).  (LDS-DMA pieces -- no staging registers -- cost this single wave 100+ cycles of issue
+  // each, 16 per chunk: steps with two pieces ran 1.8k cycles against the 1.54k of their 48 MFMAs.)
+  typedef float kmh_f4 __attribute__((ext_vector_type(4)));      // (a native vector: the asm's "=v" operand)
+  kmh_f4 rawq[3][2];
+  auto raw_issue = [&](int n, int ch, int slot, int off0, int off1) {
     const float* base = sample_base(n) + ch * chunk_stride;
-    float4* dst = reinterpret_cast<float4*>(gsm + pb * S_BUF_BYTES);
-    __builtin_amdgcn_global_load_lds((kmh_glb_ptr)(base + off0), (kmh_lds_ptr)(dst + j * S_TPB + wv * 64), 16, 0, G_AUX);
-    __builtin_amdgcn_global_load_lds((kmh_glb_ptr)(base + off1), (kmh_lds_ptr)(dst + (8 + j) * S_TPB + wv * 64), 16, 0, G_AUX);
+    const float* p0 = base + off0;
+    const float* p1 = base + off1;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rawq[slot][0]) : "v"(p0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rawq[slot][1]) : "v"(p1) : "memory");
   };
   int coef_n = -1;
   auto fill_coef = [&](int n_) {                      // (the caller's barrier publishes it)
@@ -1002,17 +1009,15 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     }
     coef_n = n_;
   };
-  // in-place conversion of the lane's voxel i of stage buffer pb (sample coef_n): branch-free, scheduled INTO a step's MFMA
-  // block; slots past the halo hold a clamped voxel's data and convert to zeros
-  auto convert1 = [&](int ch, unsigned bits, int pb, int i) {
+  // conversion of the lane's voxel i (raw halves r0, r1 in registers) into the fragment images of stage buffer pb (sample
+  // coef_n): branch-free, scheduled INTO a step's MFMA block; slots past the halo hold a clamped voxel's data and become zeros
+  auto convert1 = [&](int ch, unsigned bits, int pb, int i, const kmh_f4 r0, const kmh_f4 r1) {
     const float4 a0 = *reinterpret_cast<const float4*>(sCoef + ch * KC), a1 = *reinterpret_cast<const float4*>(sCoef + ch * KC + 4);
     const float4 b0 = *reinterpret_cast<const float4*>(sCoef + S_COEF + ch * KC), b1 = *reinterpret_cast<const float4*>(sCoef + S_COEF + ch * KC + 4);
     const float csc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
     const float csh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    float4* B4 = reinterpret_cast<float4*>(gsm + pb * S_BUF_BYTES);
     bf16x8* B8 = reinterpret_cast<bf16x8*>(gsm + pb * S_BUF_BYTES);
     const int v = tid + i * S_TPB;
-    const float4 r0 = B4[v], r1 = B4[S_PLANE + v];
     const float raw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
     const bool in = (bits >> i) & 1u;
     float val[8];
@@ -1064,21 +1069,20 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   };
   // prologue: the first stage's halo, fetched and converted with nothing to hide behind
   fill_offsets(cur);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) dma_pair(cur.n, 0, 0, j, sOff[j * S_TPB + tid], sOff[(8 + j) * S_TPB + tid]);
   unsigned cv_in = inside_bits(cur);
   fill_coef(cur.n);
   __syncthreads();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < S_NCV; ++i) convert1(0, cv_in, 0, i);
+  for (int i = 0; i < S_NCV; ++i) {
+    raw_issue(cur.n, 0, 0, sOff[i * S_TPB + tid], sOff[(8 + i) * S_TPB + tid]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    convert1(0, cv_in, 0, i, rawq[0][0], rawq[0][1]);
+  }
   o0 = lh * CoutP + cur.cog * (32 * NT) + li;             // chunk 0 of the first brick
 #pragma unroll
   for (int d = 0; d < BD; ++d) b_issue(d);
   bool first_stage = true;
   int pb = 0;                                              // stage buffer holding the CURRENT stage's fragment images
-  constexpr int CONV0 = KMH_S_CONV0;                       // first conversion step (every DMA piece was issued by step 7)
-  static_assert(CONV0 >= 8 && CONV0 + 6 <= NST, "8 voxels over the steps CONV0 .. NST - 1");
   for (;;) {
     const bool more = next_item(vb, nxt);
     const int co0 = cur.cog * (32 * NT);
@@ -1125,16 +1129,18 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
       }
 #pragma unroll
       for (int s = 0; s < NST; ++s) {
-        // this step's B fragments: leave only the B loads of the next BD - 1 steps in flight (step CONV0: nothing -- every DMA
-        // piece of the next stage has landed then; step 0 of a brick's first stage: nothing -- see `drain`)
-        if (s == CONV0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (s == 0) { if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * BL) : "memory"); }
+        // this step's B fragments and the raw voxel s - 2: everything issued up to the end of step s - 2.  Younger, and allowed
+        // to be in flight: the B loads of step s + 1 and (1 <= s <= 8) the raw voxel s - 1 -- plain loads return in order, so
+        // the count is exact.  Step 0 of a brick's first stage: nothing (see `drain`).
+        if (s == 0) { if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * BL) : "memory"); }
+        else if (s >= 1 && s <= 8) {
+          if (have_next) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * BL + 2) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * BL) : "memory");      // (no next stage: no raw loads)
+        }
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * BL) : "memory");
-        // (after the wait: the pieces issued here are the youngest entries of the queue at the next step's wait, which is
-        // then merely stricter -- and a step is ~1.5k cycles, several times a DMA's flight)
-        if (s < 8 && have_next) dma_pair(nn, nch, pb ^ 1, s, dof0, dof1);
-        if (s < 7) { dof0 = sOff[(s + 1) * S_TPB + tid]; dof1 = sOff[(9 + s) * S_TPB + tid]; }
         __builtin_amdgcn_sched_barrier(0);
+        if (s < 8 && have_next) raw_issue(nn, nch, s % 3, dof0, dof1);      // (its address arithmetic: fillers of the block)
+        if (s < 7) { dof0 = sOff[(s + 1) * S_TPB + tid]; dof1 = sOff[(9 + s) * S_TPB + tid]; }
         if (KMH_S_ADB && s + 1 < NST) {
           const int ab = vr + a_offset(s + 1);
 #pragma unroll
@@ -1149,10 +1155,8 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
 #pragma unroll
             for (int q = 0; q < TERMS; ++q) a[0][m][q] = sIn[q * S_PLANE + ab + m * HX];
         }
-        // the next stage's voxels: 2, 2, 1, 1, 1, 1 over the steps CONV0 ..
-        if (s == CONV0) { convert1(nch, cv_next, pb ^ 1, 0); convert1(nch, cv_next, pb ^ 1, 1); }
-        if (s == CONV0 + 1) { convert1(nch, cv_next, pb ^ 1, 2); convert1(nch, cv_next, pb ^ 1, 3); }
-        if (s >= CONV0 + 2 && s < CONV0 + 6) convert1(nch, cv_next, pb ^ 1, s - CONV0 + 2);
+        // the next stage's voxel s - 2 (loaded two steps ago)
+        if (s >= 2 && s < 10) convert1(nch, cv_next, pb ^ 1, s - 2, rawq[(s - 2) % 3][0], rawq[(s - 2) % 3][1]);
         // term-major over the 8 x NT accumulators: per accumulator the order of conv3_fwd_bf_kernel (smallest terms first)
 #pragma unroll
         for (int q3 = 0; q3 < 3; ++q3)
@@ -1161,14 +1165,15 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
 #pragma unroll
             for (int t = 0; t < NT; ++t)
               acc[m][t] = mfma16<TERMS>(a[KMH_S_ADB ? (s & 1) : 0][m][q3 == 0 ? 1 : 0], bq[s % BD][t][q3 == 1 ? 1 : 0], acc[m][t]);
-        if (s >= CONV0 && s < CONV0 + 6) {
-          // every LDS read of the block first (the next step's A fragments, the voxels' raw halves, the coefficients): a wait
-          // in the middle of the MFMA stream stalls it
+        if (s >= 2 && s < 10) {
+          // every LDS read of the block first (the next step's A fragments, the coefficients, the next offsets), then a few bare
+          // MFMAs while they land -- a wait in the middle of the MFMA stream stalls it --, then the conversion's VALU a few per gap
           __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, KMH_S_LEAD, 0);
 #pragma unroll
-          for (int k = 0; k < MR * NT * 3; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA ...
-            __builtin_amdgcn_sched_group_barrier(0x002, KMH_S_VPM, 0);     // ... then a few of the conversion's VALU
+          for (int k = 0; k < MR * NT * 3 - KMH_S_LEAD; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x002, KMH_S_VPM, 0);     // a few of the conversion's VALU ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // ... one MFMA
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1178,7 +1183,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
           b_issue(s % BD);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s == 0 || s == CONV0 - 1 || s == NST - 1) stamp();      // steps 0 / .. CONV0 - 1 / .. NST - 1 done
+        if (s == 0 || s == 9 || s == NST - 1) stamp();      // steps 0 / .. 9 / .. NST - 1 done
       }
       if (!last_ch) pb ^= 1;                               // (after a brick's last stage the epilogue still uses its buffer)
     }
@@ -2169,8 +2174,9 @@ KMH_API int kmh_conv3d_fwd_bf(const float* x, const float* scale, const float* s
   const bool deep = !no_deep && terms == 2 && Cout <= 32 && D >= 16 && (long long)D * H * W >= (1ll << 21);
   if (fwd_g_ok(mask != nullptr, addend != nullptr, N, D, H, W, Cin, Cout, terms)) {
     if (use_zpair(Cout)) return launch_fwd_g<1, true>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
-    // KEYMORPH_FWD_S: the one-wave-per-SIMD kernel for the 64-wide tile (1) and for 16 < Cout <= 32 too (2)
-    static const int fwd_s = getenv("KEYMORPH_FWD_S") ? atoi(getenv("KEYMORPH_FWD_S")) : 0;
+    // the one-wave-per-SIMD kernel takes the 64-wide tile and the plain 32-wide one (KEYMORPH_FWD_S=1: only the 64-wide;
+    // =0: conv3_fwd_g_kernel for both, the A/B arm)
+    static const int fwd_s = getenv("KEYMORPH_FWD_S") ? atoi(getenv("KEYMORPH_FWD_S")) : 2;
     if (fwd_s && Cin <= S_COEF && !use_zpair(Cout)) {
       if (Cout > 32) return launch_fwd_s<2>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
       if (fwd_s >= 2) return launch_fwd_s<1>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
