@@ -187,9 +187,11 @@ class _Proxy:
 
 def load():
     """dlopen the HIP library (idempotent).  Raises if it has not been built."""
-    global _lib
+    global _lib, LIBPATH
     if _lib is not None:
         return _lib
+    if os.environ.get("KEYMORPH_HIP_LIB"):      # another build of the library (A/B runs: tools/build_exp_lib.sh)
+        LIBPATH = os.environ["KEYMORPH_HIP_LIB"]
     if not os.path.exists(LIBPATH):
         raise KeymorphHipError(
             f"{LIBPATH} is missing: the HIP extension has not been built "

@@ -898,9 +898,6 @@ static_assert(GPL <= S_PLANE && GTZ == 4 && GTY == S_MR, "wave = plane, 8 rows")
 #ifndef KMH_S_VPM
 #define KMH_S_VPM 3
 #endif
-#ifndef KMH_S_CONV0
-#define KMH_S_CONV0 8
-#endif
 #ifndef KMH_S_BD
 #define KMH_S_BD 2
 #endif
@@ -989,17 +986,20 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     }
     return bits;
   };
-  // the lane's voxel j of the next stage: its two 16-byte halves into a register ring (three voxels in flight: loaded in
-  // step j, converted in step j + 2).  (LDS-DMA pieces -- no staging registers -- cost this single wave 100+ cycles of issue
+  // the lane's voxel j of the next stage: its two 16-byte halves into a register ring (two voxels: loaded in step j, landed
+  // by the drain at the head of step j + 1, converted there).  (LDS-DMA pieces -- no staging registers -- cost this single wave 100+ cycles of issue
   // each, 16 per chunk: steps with two pieces ran 1.8k cycles against the 1.54k of their 48 MFMAs.)
   typedef float kmh_f4 __attribute__((ext_vector_type(4)));      // (a native vector: the asm's "=v" operand)
-  kmh_f4 rawq[3][2];
+  kmh_f4 rawq[2][2];
   auto raw_issue = [&](int n, int ch, int slot, int off0, int off1) {
     const float* base = sample_base(n) + ch * chunk_stride;
     const float* p0 = base + off0;
     const float* p1 = base + off1;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rawq[slot][0]) : "v"(p0) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rawq[slot][1]) : "v"(p1) : "memory");
+    // (compiler-visible loads, not inline asm: a destination register of an asm load is "defined" for the compiler the moment
+    // the statement ends, so under register pressure it may copy or spill it before the data has arrived -- seen as
+    // intermittent wrong results; its own waits for these loads are merely stricter than the counted ones of the B ring)
+    rawq[slot][0] = *reinterpret_cast<const kmh_f4*>(p0);
+    rawq[slot][1] = *reinterpret_cast<const kmh_f4*>(p1);
   };
   int coef_n = -1;
   auto fill_coef = [&](int n_) {                      // (the caller's barrier publishes it)
@@ -1033,13 +1033,14 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     for (int t = 0; t < TERMS; ++t) B8[t * S_PLANE + v] = parts[t];
   };
 
-  // B fragments straight from L2 through a register ring (as conv3_fwd_g_kernel: hand-counted waits) that runs THROUGH the
-  // stage boundaries: the last BD steps of a stage load the first BD steps' fragments of the next one (a stage that starts
-  // with an empty ring pays an L2 round trip and then some: cycle stamps, step 0 took 3.3k cycles against 1.8k for the others).
-  // BD = 2 divides the 14 steps, so a step's ring slot is a compile-time constant; one wave per SIMD needs no deeper ring (a
-  // step is ~1.5k cycles, an L2 hit 200-500)
+  // B fragments straight from L2 through a two-slot register ring that runs THROUGH the stage boundaries: the fragments of step
+  // s + 1 are requested at the HEAD of step s (into the slot step s - 1 has just finished issuing from), so they have a whole
+  // step -- ~1.5k cycles, several L2 round trips -- to land, and every step opens with a plain `s_waitcnt vmcnt(0)`: no counted
+  // waits.  (Counted waits -- vmcnt(number of younger loads), the scheme of conv3_fwd_g_kernel -- gave run-to-run different
+  // results here in the steps that carry no other drain, with strict counts too; the root cause was not found, the full drain
+  // costs nothing once the loads are issued a step ahead.)
   constexpr int BD = KMH_S_BD;
-  static_assert(NST % BD == 0, "the ring slot of a step must not depend on the stage");
+  static_assert(BD == 2 && NST % BD == 0, "the ring slot of a step must not depend on the stage");
   constexpr int BL = 2 * NT;
   const long long step_stride = 2ll * CoutP, term_stride = (long long)NST * step_stride;
   bf16x8 bq[BD][NT][TERMS];
@@ -1078,10 +1079,8 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     convert1(0, cv_in, 0, i, rawq[0][0], rawq[0][1]);
   }
-  o0 = lh * CoutP + cur.cog * (32 * NT) + li;             // chunk 0 of the first brick
-#pragma unroll
-  for (int d = 0; d < BD; ++d) b_issue(d);
-  bool first_stage = true;
+  o0 = lh * CoutP + cur.cog * (32 * NT) + li;             // chunk 0 of the first brick: step 0's fragments
+  b_issue(0);
   int pb = 0;                                              // stage buffer holding the CURRENT stage's fragment images
   for (;;) {
     const bool more = next_item(vb, nxt);
@@ -1114,8 +1113,6 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
         __syncthreads();
       }
       const int co0n = ((last_ch && more) ? nxt.cog : cur.cog) * (32 * NT);      // the next stage's cout group
-      const bool drain = ch == 0 && !first_stage;          // a brick's first stage: the previous brick's output stores are in
-      first_stage = false;                                 // the queue behind the B loads (counted waits would not see past them)
       int vr = vrow;
       asm volatile("" : "+v"(vr));
       int dof0 = sOff[tid], dof1 = sOff[8 * S_TPB + tid];  // the next DMA pair's source offsets
@@ -1129,17 +1126,16 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
       }
 #pragma unroll
       for (int s = 0; s < NST; ++s) {
-        // this step's B fragments and the raw voxel s - 2: everything issued up to the end of step s - 2.  Younger, and allowed
-        // to be in flight: the B loads of step s + 1 and (1 <= s <= 8) the raw voxel s - 1 -- plain loads return in order, so
-        // the count is exact.  Step 0 of a brick's first stage: nothing (see `drain`).
-        if (s == 0) { if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * BL) : "memory"); }
-        else if (s >= 1 && s <= 8) {
-          if (have_next) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * BL + 2) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * BL) : "memory");      // (no next stage: no raw loads)
+        // everything requested so far has landed: this step's B fragments (requested at the head of the last step), the raw
+        // voxel s - 1, a previous brick's output stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (s + 1 < NST) b_issue((s + 1) % BD);               // the next step's fragments ...
+        else if (have_next) {                                 // ... or step 0's of the next stage
+          o0 = (long long)nch * TERMS * term_stride + lh * CoutP + co0n + li;
+          b_issue(0);
         }
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * BL) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (s < 8 && have_next) raw_issue(nn, nch, s % 3, dof0, dof1);      // (its address arithmetic: fillers of the block)
+        if (s < 8 && have_next) raw_issue(nn, nch, s % 2, dof0, dof1);      // (its address arithmetic: fillers of the block)
         if (s < 7) { dof0 = sOff[(s + 1) * S_TPB + tid]; dof1 = sOff[(9 + s) * S_TPB + tid]; }
         if (KMH_S_ADB && s + 1 < NST) {
           const int ab = vr + a_offset(s + 1);
@@ -1155,8 +1151,8 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
 #pragma unroll
             for (int q = 0; q < TERMS; ++q) a[0][m][q] = sIn[q * S_PLANE + ab + m * HX];
         }
-        // the next stage's voxel s - 2 (loaded two steps ago)
-        if (s >= 2 && s < 10) convert1(nch, cv_next, pb ^ 1, s - 2, rawq[(s - 2) % 3][0], rawq[(s - 2) % 3][1]);
+        // the next stage's voxel s - 1 (requested in the last step)
+        if (s >= 1 && s < 9) convert1(nch, cv_next, pb ^ 1, s - 1, rawq[(s - 1) % 2][0], rawq[(s - 1) % 2][1]);
         // term-major over the 8 x NT accumulators: per accumulator the order of conv3_fwd_bf_kernel (smallest terms first)
 #pragma unroll
         for (int q3 = 0; q3 < 3; ++q3)
@@ -1165,7 +1161,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
 #pragma unroll
             for (int t = 0; t < NT; ++t)
               acc[m][t] = mfma16<TERMS>(a[KMH_S_ADB ? (s & 1) : 0][m][q3 == 0 ? 1 : 0], bq[s % BD][t][q3 == 1 ? 1 : 0], acc[m][t]);
-        if (s >= 2 && s < 10) {
+        if (s >= 1 && s < 9) {
           // every LDS read of the block first (the next step's A fragments, the coefficients, the next offsets), then a few bare
           // MFMAs while they land -- a wait in the middle of the MFMA stream stalls it --, then the conversion's VALU a few per gap
           __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);
@@ -1177,11 +1173,6 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + BD < NST) b_issue(s % BD);     // refill the slot just consumed: step s + BD of this stage ...
-        else if (have_next) {                  // ... or step s + BD - NST of the next one
-          if (s + BD == NST) o0 = (long long)nch * TERMS * term_stride + lh * CoutP + co0n + li;
-          b_issue(s % BD);
-        }
         __builtin_amdgcn_sched_barrier(0);
         if (s == 0 || s == 9 || s == NST - 1) stamp();      // steps 0 / .. 9 / .. NST - 1 done
       }
