@@ -361,7 +361,9 @@ def test_eval_path_at_full_size_uses_the_fused_decoder_operator(world, monkeypat
     with torch.no_grad():
         plain = km.get_keypoints(world["img_f"])
     assert B.UPCONV_STATS["calls"] == before + 2
-    close(plain, res["affine"]["points_f"], 5e-6)      # (the module's earlier training test moved the weights: compare
+    # (two routes to the same numbers: different convolutions -> different epilogue statistics groupings -> GroupNorm
+    # coefficients that differ in the last bits; observed 2e-6 .. 6.4e-6 over the weights the earlier tests leave behind)
+    close(plain, res["affine"]["points_f"], 1e-5)      # (the module's earlier training test moved the weights: compare
     close(res["tps_0"]["points_f"], res["rigid"]["points_f"], 0)       # within this test, not with world["pts_f"])
 
 
