@@ -446,3 +446,69 @@ def test_first_layer_correlation_kernel_vs_fp64(cfg):
     scale = float((cotm.double().abs() * pre.detach().abs()).sum()) + 1e-30
     assert abs(float(Hh[0].grad) - float(R[0].grad)) < 1e-6 * scale
     assert abs(float(Hh[1].grad) - float(R[1].grad)) < 1e-6 * scale
+
+
+def test_forward_kernels_repeat_bit_for_bit_with_other_work_in_between():
+    """conv3_fwd_s_kernel (one wave per SIMD, the default for 16 < Cout) waits for its loads with plain full drains; an earlier
+    version counted them and gave run-to-run different results inside a training step (never back to back on warm caches).
+    Here the same launch is repeated with a cache-flushing copy and another convolution in between: outputs and epilogue
+    statistics must be bit-equal every time -- the 64-wide tile, the 32-wide one, a channel-blocked data gradient."""
+    from keymorph_amd import backbone_ops as B
+    old = B.CONV_MODE
+    try:
+        B.set_conv_mode("f16x3")
+        g = gen(77)
+        junk = torch.empty(96 * 1024 * 1024, device=DEV)                      # 384 MB: past L2 + the infinity cache
+        for (N, D, Cin, Cout, blocked) in ((2, 64, 64, 64, False), (4, 64, 32, 32, False), (2, 64, 64, 32, True)):
+            x = torch.randn(N, D, D, D, Cin, generator=g).to(DEV)
+            # (the data gradient Cin -> Cout uses the FORWARD layer's filter (Cin, Cout, 3, 3, 3), packed transposed)
+            w = (torch.randn(*((Cin, Cout) if blocked else (Cout, Cin)), 3, 3, 3, generator=g) / np.sqrt(27 * Cin)).to(DEV)
+            pk = B.pack_weight(w, blocked)
+            xin = x.view(N, D, D, D, Cin // 8, 8).permute(0, 4, 1, 2, 3, 5).contiguous() if blocked else x
+            asc = B.absmax_scale(x)
+            other = torch.randn(1, 40, 40, 40, 16, generator=g).to(DEV)
+            pko = B.pack_weight((torch.randn(32, 16, 3, 3, 3, generator=g) * 0.05).to(DEV), False)
+            ref = None
+            for rep in range(6):
+                st = torch.full((N, Cout, 2), float("nan"), dtype=torch.float64, device=DEV)
+                y = B.conv3_raw(xin, None, None, pk, None, N, D, D, D, Cin, Cout, False, not blocked, ascale=asc, stats_out=st,
+                                in_blocked=blocked)
+                if ref is None:
+                    ref = (y.clone(), st.clone())
+                else:
+                    assert torch.equal(y, ref[0]) and torch.equal(st, ref[1]), (N, D, Cin, Cout, blocked, rep)
+                junk.fill_(float(rep))                                            # evict the weights and the halo
+                B.conv3_raw(other, None, None, pko, None, 1, 40, 40, 40, 16, 32, False, True)
+    finally:
+        B.set_conv_mode(old)
+
+
+def test_the_eight_wave_kernel_still_matches(tmp_path):
+    """KEYMORPH_FWD_S=0 keeps conv3_fwd_g_kernel<2,false> / <1,false> as the A/B arm of conv3_fwd_s_kernel: its outputs must
+    stay bit-identical to the default's (the switch is read once per process, so the other arm runs in a child)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+        "from keymorph_amd import backbone_ops as B, _lib\n"
+        "B.set_conv_mode('f16x3'); lib = _lib.load(); lib.kmh_conv3d_fwd_bf_set_dispatch(2)\n"
+        "g = torch.Generator().manual_seed(5); outs = {}\n"
+        "for (N, dims, Cin, Cout) in ((2, (30, 61, 121), 64, 64), (2, (45, 60, 100), 32, 32)):\n"
+        "    D, H, W = dims\n"
+        "    x = torch.randn(N, D, H, W, Cin, generator=g).cuda(); w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.05).cuda()\n"
+        "    sc = (1 + 0.3 * torch.randn(N, Cin, generator=g)).cuda(); sh = (0.3 * torch.randn(N, Cin, generator=g)).cuda()\n"
+        "    asc = B.absmax_scale(x * 2.5)\n"
+        "    y = B.conv3_raw(x, sc, sh, B.pack_weight(w, False), None, N, D, H, W, Cin, Cout, False, True, ascale=asc)\n"
+        "    outs['%%d_%%d' %% (Cin, Cout)] = y.cpu().numpy()\n"
+        "np.savez(sys.argv[1], **outs)\n" % root)
+    files = {}
+    for arm in ("0", "2"):
+        files[arm] = str(tmp_path / f"arm{arm}.npz")
+        r = subprocess.run([sys.executable, "-c", code, files[arm]], env=dict(os.environ, KEYMORPH_FWD_S=arm),
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(files["0"]), np.load(files["2"])
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
