@@ -1189,7 +1189,8 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     constexpr int VPI = 64 / L4;
     const long long sbrick = ((long long)n * tiles_z * tiles_y * tiles_x + ((long long)cur.bz * tiles_y + cur.by) * tiles_x + cur.bx);
     unsigned char* sEp = gsm + pb * S_BUF_BYTES;
-    float* tile = reinterpret_cast<float*>(sEp) + wv * (32 * CH);
+    float* tile0 = reinterpret_cast<float*>(sEp) + wv * (2 * 32 * CH);      // two tiles per wave: row m + 1 is written while
+                                                                          // row m's read-back and stores are in flight
     const int c4 = lane % L4, vx = lane / L4;
     const int col = 4 * c4;
     const int co = co0 + col;
@@ -1201,6 +1202,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     const int gz = z0 + wv;
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
+      float* tile = tile0 + (m & 1) * (32 * CH);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
