@@ -200,7 +200,7 @@ def roofline(mode, conv_tf):
     peak = MFMA_BF16_PEAK_TFLOPS / mult
     traffic, src = pmc_traffic("conv3_fwd_")      # conv3_fwd_g_kernel (LDS-DMA staging) + conv3_fwd_bf_kernel
     return {"bound": "mfma",
-            "kernel": f"conv3_fwd_g_kernel / conv3_fwd_bf_kernel behind kmh_conv3d_fwd_bf (fp32 results from {mult} x "
+            "kernel": f"conv3_fwd_s_kernel / conv3_fwd_g_kernel / conv3_fwd_bf_kernel behind kmh_conv3d_fwd_bf (fp32 results from {mult} x "
                       f"{insn} per product block, fp32 accumulate)",
             "achieved": conv_tf, "peak": peak, "unit": "TFLOP/s", "frac": conv_tf / peak,
             "mfma_util": conv_tf * mult / MFMA_BF16_PEAK_TFLOPS,
