@@ -904,6 +904,9 @@ static_assert(GPL <= S_PLANE && GTZ == 4 && GTY == S_MR, "wave = plane, 8 rows")
 #ifndef KMH_S_LEAD
 #define KMH_S_LEAD 6
 #endif
+#ifndef KMH_S_RF
+#define KMH_S_RF 1
+#endif
 #ifndef KMH_S_ADB
 #define KMH_S_ADB 1
 #endif
@@ -1105,9 +1108,8 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
       const bf16x8* sIn = reinterpret_cast<const bf16x8*>(gsm + pb * S_BUF_BYTES);      // [TERMS][S_PLANE]
       const bool last_ch = ch + 1 == nchunk;
       const bool have_next = !last_ch || more;
-      if (last_ch && more) fill_offsets(nxt);
       const int nn = (last_ch && more) ? nxt.n : n, nch = last_ch ? 0 : ch + 1;      // (no next stage: any valid pair)
-      const unsigned cv_next = last_ch ? (more ? inside_bits(nxt) : 0u) : cv_in;
+      unsigned cv_next = last_ch ? 0u : cv_in;             // (the next BRICK's table and bits: inside step 0, below)
       if (nn != coef_n) {                                  // uniform, rare: the work list moves on to another sample
         fill_coef(nn);
         __syncthreads();
@@ -1115,7 +1117,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
       const int co0n = ((last_ch && more) ? nxt.cog : cur.cog) * (32 * NT);      // the next stage's cout group
       int vr = vrow;
       asm volatile("" : "+v"(vr));
-      int dof0 = sOff[tid], dof1 = sOff[8 * S_TPB + tid];  // the next DMA pair's source offsets
+      int dof0 = 0, dof1 = 0;                              // the next raw voxel's source offsets (read one step ahead)
       bf16x8 a[KMH_S_ADB ? 2 : 1][MR][TERMS];              // this step's A fragments (and the next step's)
       {
         const int ab = vr + a_offset(0);
@@ -1135,8 +1137,12 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
           b_issue(0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s < 8 && have_next) raw_issue(nn, nch, s % 2, dof0, dof1);      // (its address arithmetic: fillers of the block)
-        if (s < 7) { dof0 = sOff[(s + 1) * S_TPB + tid]; dof1 = sOff[(9 + s) * S_TPB + tid]; }
+        // the next stage's voxel s - 1 is requested in step s (1..8) and converted in step s + 1.  Step 0 of a brick's last stage
+        // first replaces the offset table and the inside bits by the next brick's (~400 VALU: fillers here, 3k cycles at the
+        // stage top before)
+        if (s == 0 && last_ch && more) { fill_offsets(nxt); cv_next = inside_bits(nxt); }
+        if (s >= 1 && s < 9 && have_next) raw_issue(nn, nch, (s - 1) % 2, dof0, dof1);
+        if (s < 8) { dof0 = sOff[s * S_TPB + tid]; dof1 = sOff[(8 + s) * S_TPB + tid]; }
         if (KMH_S_ADB && s + 1 < NST) {
           const int ab = vr + a_offset(s + 1);
 #pragma unroll
@@ -1151,8 +1157,8 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
 #pragma unroll
             for (int q = 0; q < TERMS; ++q) a[0][m][q] = sIn[q * S_PLANE + ab + m * HX];
         }
-        // the next stage's voxel s - 1 (requested in the last step)
-        if (s >= 1 && s < 9) convert1(nch, cv_next, pb ^ 1, s - 1, rawq[(s - 1) % 2][0], rawq[(s - 1) % 2][1]);
+        // the next stage's voxel s - 2 (requested in the last step)
+        if (s >= 2 && s < 10) convert1(nch, cv_next, pb ^ 1, s - 2, rawq[(s - 2) % 2][0], rawq[(s - 2) % 2][1]);
         // term-major over the 8 x NT accumulators: per accumulator the order of conv3_fwd_bf_kernel (smallest terms first)
 #pragma unroll
         for (int q3 = 0; q3 < 3; ++q3)
@@ -1161,7 +1167,8 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
 #pragma unroll
             for (int t = 0; t < NT; ++t)
               acc[m][t] = mfma16<TERMS>(a[KMH_S_ADB ? (s & 1) : 0][m][q3 == 0 ? 1 : 0], bq[s % BD][t][q3 == 1 ? 1 : 0], acc[m][t]);
-        if (s >= 1 && s < 9) {
+        if (!(s >= 2 && s < 10) && KMH_S_RF) __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);      // plain steps: reads first too
+        if (s >= 2 && s < 10) {
           // every LDS read of the block first (the next step's A fragments, the coefficients, the next offsets), then a few bare
           // MFMAs while they land -- a wait in the middle of the MFMA stream stalls it --, then the conversion's VALU a few per gap
           __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);
