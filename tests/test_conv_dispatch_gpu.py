@@ -512,3 +512,36 @@ def test_the_eight_wave_kernel_still_matches(tmp_path):
     a, b = np.load(files["0"]), np.load(files["2"])
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_training_steps_repeat_bit_for_bit(dispatch):
+    """Three optimisation steps of a small TruncatedUNet3D keypoint model with the LDS-DMA / one-wave kernels forced onto its
+    volumes, twice from the same initial state: identical parameters, bit for bit (every reduction has a fixed order; the
+    forward kernel's waits are full drains -- with counted waits this is what differed from run to run)."""
+    from keymorph_amd import backbone_ops as B, parallel
+    from keymorph_amd.unet3d.model import TruncatedUNet3D
+    old = B.CONV_MODE
+    try:
+        B.set_conv_mode("f16x3")
+        dispatch(2)
+        img = torch.rand(2, 1, 24, 40, 64, generator=gen(31)).to(DEV)
+        tgt = torch.randn(2, 16, 3, generator=gen(32)).to(DEV)
+        junk = torch.empty(64 * 1024 * 1024, device=DEV)
+
+        def run():
+            torch.manual_seed(7)
+            net = TruncatedUNet3D(1, 16, 1, final_sigmoid=False, f_maps=32, layer_order="gcr", num_groups=8, num_levels=3,
+                                  is_segmentation=False, conv_padding=1).to(DEV).train()
+            flat = parallel.FlatParams(net.parameters())
+            opt = parallel.FusedAdam(flat, lr=1e-3)
+            for it in range(3):
+                flat.zero_grad()
+                ((net.keypoints_ij(img) - tgt) ** 2).mean().backward()
+                junk.fill_(float(it))                         # cold caches for the next step's first launches
+                opt.step(flat.allreduce_grads())
+            return flat.flat.clone()
+
+        a, b = run(), run()
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    finally:
+        B.set_conv_mode(old)
