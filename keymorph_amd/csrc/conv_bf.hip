@@ -911,21 +911,25 @@ static_assert(GPL <= S_PLANE && GTZ == 4 && GTY == S_MR, "wave = plane, 8 rows")
 #define KMH_S_ADB 1
 #endif
 
-template <int NT>
+// ZP (Cout <= 16, z-paired weights, NT = 1): wave = (plane pair, row half) -- 4 rows, the N tile is (16 couts x 2 planes) over the
+// pair's 4-plane input window, 18 tap-pair steps of 12 MFMAs (the eight-wave kernel: 6 per wave and step, the most
+// overhead-bound launch of the step).
+template <int NT, bool ZP = false>
 __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16x8* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int D, int H, int W, int Cin,
     int Cout, int CoutP, int relu_in, int relu_out, int tiles_x, int tiles_y, int tiles_z, int tiles_zp,
     const float* __restrict__ ascale, const float* __restrict__ wscale, double* __restrict__ stats_partial,
     int in_blocked, const float* __restrict__ addend, int total_items, int N, long long* __restrict__ trace) {
-  constexpr int TERMS = 2, MR = S_MR, NST = NSTEP;
+  constexpr int TERMS = 2, MR = ZP ? 4 : S_MR, NST = ZP ? NSTEP_Z : NSTEP;
+  static_assert(!ZP || NT == 1, "z-paired tiles are for Cout <= 16");
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   int* sOff = reinterpret_cast<int*>(gsm + 2 * S_BUF_BYTES);
   float* sCoef = reinterpret_cast<float*>(gsm + 2 * S_BUF_BYTES + S_OFF_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int ncog = (Cout + 32 * NT - 1) / (32 * NT);
+  const int ncog = ZP ? 1 : (Cout + 32 * NT - 1) / (32 * NT);
   const int tyz = (tiles_y + 7) >> 3;
   struct Item { int n, cog, bx, by, bz; };
   const int total_all = N * total_items;
@@ -953,7 +957,8 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   const float sA = ascale ? ascale[0] : 1.f;
   const float desc = (ascale ? ascale[1] : 1.f) * (wscale ? wscale[1] : 1.f);
   const int nchunk = Cin / KC;
-  const int vrow = (wv * GHY) * HX + li;                  // wave = output plane wv, rows 0..7
+  const int wz = ZP ? 2 * (wv >> 1) : wv, wy = ZP ? (wv & 1) * MR : 0;      // first output plane / row of the wave
+  const int vrow = (wz * GHY + wy) * HX + li;
   const long long vox = (long long)D * H * W;
   const long long chunk_stride = in_blocked ? vox * KC : KC;
   auto sample_base = [&](int n) { return in_blocked ? x + (long long)n * nchunk * vox * KC : x + (long long)n * vox * Cin; };
@@ -1060,7 +1065,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     o0 += step_stride;
   };
   auto a_offset = [&](int s) -> int {                    // LDS slot offset of this lane's A fragment of step s, row 0
-    constexpr int last_tap = 26;
+    constexpr int last_tap = ZP ? 35 : 26;
     const int tapA = 2 * s, tapB = (2 * s + 1 > last_tap) ? last_tap : 2 * s + 1;      // padded half-step: zero weights
     const int offA = ((tapA / 9) * GHY + (tapA / 3) % 3) * HX + tapA % 3;
     const int offB = ((tapB / 9) * GHY + (tapB / 3) % 3) * HX + tapB % 3;
@@ -1200,13 +1205,14 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
                                                                           // row m's read-back and stores are in flight
     const int c4 = lane % L4, vx = lane / L4;
     const int col = 4 * c4;
-    const int co = co0 + col;
+    const int pl = ZP ? col >> 4 : 0;                          // ZP: column = (channel, output plane of the pair)
+    const int co = ZP ? (col & 15) : co0 + col;
     const bool co_ok = co < Cout;
     float4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias && co_ok) bv = *reinterpret_cast<const float4*>(bias + co);
     float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                           // every wave is done with the fragment images
-    const int gz = z0 + wv;
+    const int gz = z0 + wz + pl;
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
       float* tile = tile0 + (m & 1) * (32 * CH);
@@ -1214,7 +1220,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * CH + 32 * t + li] = acc[m][t][r];
-      const int gy = y0 + m;
+      const int gy = y0 + wy + m;
       const bool row_ok = gz < D && gy < H && co_ok;
       const long long rowoff = ((((long long)n * D + gz) * H + gy) * W) * Cout + co;
       float4 v4[32 / VPI], ad[32 / VPI];
@@ -1254,14 +1260,20 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
         for (int j = 0; j < 4; ++j) { sred[((wv * CH) + col + j) * 2] = d1[j]; sred[((wv * CH) + col + j) * 2 + 1] = d2[j]; }
       }
       __syncthreads();
-      if (tid < 2 * CH) {
+      const int ncol = ZP ? 16 : CH;
+      if (tid < 2 * ncol) {
         const int k = tid & 1, c = tid >> 1;
-        const int cch = co0 + c;
+        const int cch = ZP ? c : co0 + c;
         if (cch < Cout) {
-          // (the outputs are bit-identical to conv3_fwd_g_kernel's; these sums group them by plane instead of by
+          // (the outputs are bit-identical to conv3_fwd_g_kernel's; these sums group them by wave = plane (pair) instead of by
           // (plane, row half), so they agree with that kernel's to fp32 rounding of the per-lane partial sums, not bit for bit)
-          stats_partial[(sbrick * Cout + cch) * 2 + k] = (sred[(0 * CH + c) * 2 + k] + sred[(1 * CH + c) * 2 + k]) +
-                                                        (sred[(2 * CH + c) * 2 + k] + sred[(3 * CH + c) * 2 + k]);
+          double sum = 0.0;
+#pragma unroll
+          for (int w4 = 0; w4 < 4; ++w4) {
+            sum += sred[(w4 * CH + c) * 2 + k];
+            if (ZP) sum += sred[(w4 * CH + 16 + c) * 2 + k];   // the second plane of the pair
+          }
+          stats_partial[(sbrick * Cout + cch) * 2 + k] = sum;
         }
       }
     }
@@ -2031,17 +2043,17 @@ static int launch_fwd_g(const float* x, const float* scale, const float* shift, 
   return KMH_LAUNCH_CHECK();
 }
 
-template <int NT>
+template <int NT, bool ZP = false>
 static int launch_fwd_s(const float* x, const float* scale, const float* shift, const bf16x8* wp, const float* bias, float* y,
                         int N, int D, int H, int W, int Cin, int Cout, int CoutP, int relu_in, int relu_out,
                         const float* ascale, const float* wscale, double* stats_ws, double* stats_out, hipStream_t s,
                         int in_blocked, const float* addend) {
-  hipError_t e = hipFuncSetAttribute((const void*)conv3_fwd_s_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute((const void*)conv3_fwd_s_kernel<NT, ZP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      S_LDS_BYTES);
   if (e != hipSuccess) return (int)e;
   const int tx = ceil_div(W, TX), ty = ceil_div(H, GTY), tz = ceil_div(D, GTZ);
   const int typ = ceil_div(ty, 8), tzp = ceil_div(tz, 8);
-  const int total = tx * typ * tzp * 64 * ceil_div(Cout, 32 * NT);      // virtual blocks per sample
+  const int total = tx * typ * tzp * 64 * (ZP ? 1 : ceil_div(Cout, 32 * NT));      // virtual blocks per sample
   long long all = (long long)N * total;
   int wgs = 256;                                          // persistent, one per CU
   if (wgs > ((all + 7) / 8) * 8) wgs = (int)(((all + 7) / 8) * 8);
@@ -2049,7 +2061,7 @@ static int launch_fwd_s(const float* x, const float* scale, const float* shift, 
   static const bool tracing = getenv("KMH_G_TRACE") != nullptr;
   if (tracing && !trace) { if (hipMalloc(&trace, 240 * sizeof(long long)) != hipSuccess) trace = nullptr; }
   if (tracing && trace) (void)hipMemsetAsync(trace, 0, 240 * sizeof(long long), s);
-  conv3_fwd_s_kernel<NT><<<dim3(wgs), S_TPB, S_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in,
+  conv3_fwd_s_kernel<NT, ZP><<<dim3(wgs), S_TPB, S_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in,
                                                                relu_out, tx, ty, tz, tzp, ascale, wscale,
                                                                stats_out ? stats_ws : nullptr, in_blocked, addend, total, N,
                                                                tracing ? trace : nullptr);
@@ -2057,7 +2069,7 @@ static int launch_fwd_s(const float* x, const float* scale, const float* shift, 
     long long h[240];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "KMH_G_TRACE fwd_s NT=%d Cin=%d Cout=%d D=%d:", NT, Cin, Cout, D);
+    fprintf(stderr, "KMH_G_TRACE fwd_s NT=%d ZP=%d Cin=%d Cout=%d D=%d:", NT, (int)ZP, Cin, Cout, D);
     for (int i = 1; i < 240 && h[i]; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
     fprintf(stderr, "\n");
   }
@@ -2173,10 +2185,13 @@ KMH_API int kmh_conv3d_fwd_bf(const float* x, const float* scale, const float* s
   static const bool no_deep = getenv("KEYMORPH_FWD_NO_DEEP") != nullptr;     // A/B measurements only
   const bool deep = !no_deep && terms == 2 && Cout <= 32 && D >= 16 && (long long)D * H * W >= (1ll << 21);
   if (fwd_g_ok(mask != nullptr, addend != nullptr, N, D, H, W, Cin, Cout, terms)) {
-    if (use_zpair(Cout)) return launch_fwd_g<1, true>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
-    // the one-wave-per-SIMD kernel takes the 64-wide tile and the plain 32-wide one (KEYMORPH_FWD_S=1: only the 64-wide;
-    // =0: conv3_fwd_g_kernel for both, the A/B arm)
+    // the one-wave-per-SIMD kernel takes the 64-wide tile and the plain 32-wide one (KEYMORPH_FWD_S=1: only the 64-wide; 3: the
+    // z-paired tile too -- bit-identical, 3.7 % faster alone at 2 x 256^3 and flat inside the step, so not the default;
+    // 0: conv3_fwd_g_kernel for all of them, the A/B arm)
     static const int fwd_s = getenv("KEYMORPH_FWD_S") ? atoi(getenv("KEYMORPH_FWD_S")) : 2;
+    if (fwd_s >= 3 && Cin <= S_COEF && use_zpair(Cout) && !addend)
+      return launch_fwd_s<1, true>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
+    if (use_zpair(Cout)) return launch_fwd_g<1, true>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
     if (fwd_s && Cin <= S_COEF && !use_zpair(Cout)) {
       if (Cout > 32) return launch_fwd_s<2>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
       if (fwd_s >= 2) return launch_fwd_s<1>(x, scale, shift, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, ascale, wscale, (double*)stats_ws, stats_out, s, in_blocked, addend);
