@@ -68,6 +68,10 @@ int kmh_rows_axpby(const float* t, const float* p, const float* ca, const float*
  *      the Dice sums (keymorph/loss_ops.py:28-52) WITHOUT storing the warped segmentation.
  *      sums[(n*C + c)*3 + {0,1,2}] = {sum t p, sum p^2, sum t^2}, p = grid_sample(x, grid)[n,c], t = fixed[n,c].
  *      -22 when the lane-contiguous sampler does not apply (W < 2, plane >= 2^31 voxels, C > 128). */
+/* 1 when the fused warp + Dice entry points below serve these sizes (they return -22 otherwise): W >= 2, < 2^30 voxels per
+ * channel plane, C <= 128, N * C <= 65536, the lane-contiguous sampler not switched off (KMH_SAMPLER_OLD).  The host asks
+ * BEFORE building an autograd node and otherwise composes keymorph/utils.py:14-21 with keymorph/loss_ops.py:16-63 unfused. */
+int kmh_warp_dice_ok(int N, int C, int D, int H, int W);
 int kmh_warp_dice_sums(const float* x, const float* grid, const float* fixed, float* sums, int N, int C, int D, int H,
                        int W, int Do, int Ho, int Wo, const unsigned char* lab_x, const unsigned char* lab_fixed,
                        const int* gate, void* ws, void* stream);
@@ -126,6 +130,11 @@ int kmh_tps_points_bwd(const float* dout, const float* theta, const float* ctrl,
 size_t kmh_tps_fit_ws_bytes(int N, int T);
 int kmh_tps_fit_fwd(const float* ctrl, const float* tgt, const float* lmbda, const float* w, float* theta,
                     int N, int T, void* ws, void* stream);
+/* Large systems are factorised by a cluster of workgroups per system that hand panels over through global counters; a
+ * cluster that could not get all its workgroups resident gives up (bounded waits) and the SAME call redoes that system on
+ * the one-workgroup kernel (device-side retry pass, no host round trip).  Test hook: the next `count` clustered calls mark
+ * every system as "gave up" so that the retry pass does all the work; returns the previous count. */
+int kmh_tps_fit_force_retry(int count);
 /* backward: given dtheta -> dctrl, dtgt (uses the factors in ws written by the forward) and, when the fit was
  * weighted and dw != NULL, dw (N,T) = d/dw of the lmbda / (w + 1e-6) diagonal. */
 int kmh_tps_fit_bwd(const float* dtheta, const float* theta, const float* ctrl, const float* lmbda, const float* w,

@@ -30,6 +30,7 @@ PROTOS = {
     "kmh_scale_unless_one": (_i, [_f, _ll, _f, _f]),
     "kmh_dice_sums": (_i, [_f, _f, _i, _ll, _f, _f, _f]),
     "kmh_rows_axpby": (_i, [_f, _f, _f, _f, _i, _ll, _f, _f]),
+    "kmh_warp_dice_ok": (_i, [_i, _i, _i, _i, _i]),
     "kmh_warp_dice_sums": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
     "kmh_warp_dice_bwd_grid": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "kmh_onehot_to_labels": (_i, [_f, _i, _i, _ll, _f, _f, _f]),
@@ -44,6 +45,7 @@ PROTOS = {
     "kmh_tps_points_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _f]),
     "kmh_tps_fit_ws_bytes": (_sz, [_i, _i]),
     "kmh_tps_fit_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _f, _f]),
+    "kmh_tps_fit_force_retry": (_i, [_i]),
     "kmh_tps_fit_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f]),
     "kmh_affine_fit_fwd": (_i, [_f, _f, _f, _f, _i, _i, _f]),
     "kmh_affine_fit_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f]),

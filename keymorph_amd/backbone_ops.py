@@ -1162,8 +1162,12 @@ LAZY_IN_STATS = {"units": 0}
 
 def convnet_lazy_ok(x: Tensor, norm_type: str) -> bool:
     """(N, D, H, W, C) NDHWC input of the ConvNet: four poolings need D, H, W % 16 == 0 for the even-size kernels; the
-    split-operand convolutions emit the statistics; KEYMORPH_NO_LAZY_IN=1 takes the block-by-block route (A/B, tests)."""
+    split-operand convolutions emit the statistics; KEYMORPH_NO_LAZY_IN=1 takes the block-by-block route (A/B, tests).
+    The fused units never form the gradient w.r.t. the image (their first unit returns None for it), so an input that
+    requires one -- saliency maps, adversarial inputs, augmentation differentiated through the image -- takes the
+    block-by-block route, whose first block does compute it."""
     return (norm_type == "instance" and conv_emits_stats() and not os.environ.get("KEYMORPH_NO_LAZY_IN")
+            and not (x.requires_grad and torch.is_grad_enabled())
             and all(int(d) % 16 == 0 for d in x.shape[1:4]))
 
 

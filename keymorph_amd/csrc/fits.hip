@@ -9,6 +9,7 @@
 // panel + U12 strip in LDS, wavefront-shuffle pivot search) and solved for the 3 right-hand
 // sides together; the factors stay in the workspace so the backward (A is symmetric, so
 // A^T g = dtheta is the same solve) costs one more substitution, not a factorisation.
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -444,8 +445,10 @@ constexpr int LU_TPB = 1024;
 __global__ __launch_bounds__(256) void tps_assemble_kernel(const float* __restrict__ ctrl,
                                                            const float* __restrict__ lmbda,
                                                            const float* __restrict__ w, double* __restrict__ A,
-                                                           int T, int lda, size_t a_stride) {
+                                                           int T, int lda, size_t a_stride,
+                                                           const int* __restrict__ retry_info = nullptr) {
   const int b = blockIdx.z;
+  if (retry_info && retry_info[b] != 2) return;      // retry pass: only the systems whose cluster factorisation gave up
   const int n = T + 4;
   const int j = blockIdx.x * 16 + (threadIdx.x & 15);
   const int i = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -489,7 +492,8 @@ __global__ __launch_bounds__(256) void tps_assemble_kernel(const float* __restri
 template <int NB, bool MFMA64>
 __global__ __launch_bounds__(LU_TPB) void tps_lu_kernel(double* __restrict__ Aall, int* __restrict__ ipiv_all,
                                                         int* __restrict__ info_all, int n, int lda,
-                                                        size_t a_stride) {
+                                                        size_t a_stride, int retry_only = 0) {
+  if (retry_only && info_all[blockIdx.x] != 2) return;      // (uniform per workgroup: before any barrier)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int PS = NB + 1;
   double* sP = smem;                       // [n][PS]
@@ -1045,7 +1049,8 @@ __global__ __launch_bounds__(LU_TPB) void tps_solve_kernel(const double* __restr
     __syncthreads();
   }
   // info == 2: the factorisation gave up waiting for a workgroup of its cluster (tps_lu_cluster_kernel: its workgroups were not
-  // all resident).  That must not pass as a result: the coefficients become NaN, which every caller's finiteness check sees.
+  // all resident) AND the retry pass of kmh_tps_fit_fwd did not replace it (it always does: tps_lu_kernel reports 0 or 1).
+  // Belt and braces: such a result must not pass as coefficients, so it becomes NaN.
   const bool poisoned = info_all && info_all[blockIdx.x] == 2;
   for (int e = tid; e < n * 3; e += LU_TPB) {
     const double v = poisoned ? __longlong_as_double(0x7ff8000000000000ll) : sb[e];
@@ -1235,8 +1240,25 @@ KMH_API size_t kmh_tps_fit_ws_bytes(int N, int T) {
          (size_t)N * n * sizeof(int) * 2 + (size_t)N * sizeof(int) * 5 + 512;
 }
 
+// Compute units of the current device (one query per process and device; 0 on failure: the cluster kernel is then not used)
+static int device_cus() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    v = cus > 0 ? cus : -1;
+    cached[dev].store(v, std::memory_order_relaxed);
+  }
+  return v > 0 ? v : 0;
+}
+
+// *used_cluster = 1 when the cluster kernel was launched (the caller then queues the retry pass behind it)
 template <int NB>
-static int launch_lu(const FitWs& f, int N, int n, hipStream_t s) {
+static int launch_lu(const FitWs& f, int N, int n, hipStream_t s, int* used_cluster) {
+  *used_cluster = 0;
   const size_t lds = ((size_t)n * (NB + 1) + (size_t)NB * n) * sizeof(double) + (size_t)n * sizeof(int);   // + rowmap
   if (lds > 160 * 1024 - 1024) return -22;
   static const bool valu_trailing = getenv("KEYMORPH_TPS_LU_VALU") != nullptr;      // A/B measurements only
@@ -1248,18 +1270,30 @@ static int launch_lu(const FitWs& f, int N, int n, hipStream_t s) {
     return KMH_LAUNCH_CHECK();
   }
   // cluster of G workgroups per system when the systems are large enough to pay for the hand-offs and every workgroup of the
-  // launch is resident at once (one per CU: 136 KB of LDS): KEYMORPH_TPS_LU_CLUSTER=<G> (0 / 1 = one workgroup per system)
+  // launch can be resident at once (one per CU: 136 KB of LDS): KEYMORPH_TPS_LU_CLUSTER=<G> (0 / 1 = one workgroup per system).
+  // The workgroups synchronise through global counters inside an ORDINARY launch, so residency is a matter of the grid size:
+  // the grid stays within HALF the device's compute units (queried, not assumed) and the occupancy query must admit the kernel
+  // at all.  That leaves room for a neighbour on another stream, but proves nothing about CUs held by other processes or a CU
+  // mask -- which is why every wait in the kernel is bounded and a fit that gave up (info = 2) is REDONE on the one-workgroup
+  // kernel by the retry pass queued behind it (kmh_tps_fit_fwd): the caller never sees a poisoned result.
   static const int genv = getenv("KEYMORPH_TPS_LU_CLUSTER") ? atoi(getenv("KEYMORPH_TPS_LU_CLUSTER")) : 8;
+  const int cus = device_cus();
   int G = genv;
-  while (G > 1 && (long long)N * G > 128) G >>= 1;
+  while (G > 1 && (long long)N * G * 2 > cus) G >>= 1;
   if (G > 1 && n >= 128) {
     hipError_t e = hipFuncSetAttribute((const void*)tps_lu_cluster_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(f.sync, 0, (size_t)N * 4 * sizeof(int), s);
-    if (e != hipSuccess) return (int)e;
-    tps_lu_cluster_kernel<NB><<<dim3(G, N), LU_TPB, lds, s>>>(f.A, f.ipiv, f.info, n, f.lda, f.a_stride, f.pivs, f.sync);
-    return KMH_LAUNCH_CHECK();
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)tps_lu_cluster_kernel<NB>, LU_TPB, lds);
+    if (e != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+    if (per_cu >= 1) {
+      e = hipMemsetAsync(f.sync, 0, (size_t)N * 4 * sizeof(int), s);
+      if (e != hipSuccess) return (int)e;
+      tps_lu_cluster_kernel<NB><<<dim3(G, N), LU_TPB, lds, s>>>(f.A, f.ipiv, f.info, n, f.lda, f.a_stride, f.pivs, f.sync);
+      *used_cluster = 1;
+      return KMH_LAUNCH_CHECK();
+    }
   }
   hipError_t e = hipFuncSetAttribute((const void*)tps_lu_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
@@ -1268,6 +1302,34 @@ static int launch_lu(const FitWs& f, int N, int n, hipStream_t s) {
   return KMH_LAUNCH_CHECK();
 }
 
+// the systems a cluster factorisation gave up on (info = 2), once more on the one-workgroup kernel: both launches return at
+// once for every other system (a few microseconds), no host round trip
+template <int NB>
+static int launch_lu_retry(const FitWs& f, const float* ctrl, const float* lmbda, const float* w, int N, int T,
+                           hipStream_t s) {
+  const int n = T + 4;
+  const size_t lds = ((size_t)n * (NB + 1) + (size_t)NB * n) * sizeof(double) + (size_t)n * sizeof(int);
+  hipError_t e = hipFuncSetAttribute((const void*)tps_lu_kernel<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) return (int)e;
+  tps_assemble_kernel<<<dim3(ceil_div(n, 16), ceil_div(n, 16), N), 256, 0, s>>>(ctrl, lmbda, w, f.A, T, f.lda, f.a_stride,
+                                                                             f.info);
+  tps_lu_kernel<NB, true><<<N, LU_TPB, lds, s>>>(f.A, f.ipiv, f.info, n, f.lda, f.a_stride, 1);
+  return KMH_LAUNCH_CHECK();
+}
+
+/* Test hook: the next `count` calls of kmh_tps_fit_fwd that use the cluster factorisation mark every system as "gave up"
+ * (info = 2) before the retry pass, which must then reproduce the one-workgroup result.  Returns the previous count. */
+static std::atomic<int> g_force_retry{0};
+KMH_API int kmh_tps_fit_force_retry(int count) { return g_force_retry.exchange(count < 0 ? 0 : count); }
+
+namespace {
+__global__ void tps_mark_retry_kernel(int* __restrict__ info, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) info[i] = 2;
+}
+}  // namespace
+
 KMH_API int kmh_tps_fit_fwd(const float* ctrl, const float* tgt, const float* lmbda, const float* w,
                             float* theta, int N, int T, void* ws, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -1275,11 +1337,18 @@ KMH_API int kmh_tps_fit_fwd(const float* ctrl, const float* tgt, const float* lm
   FitWs f = carve(ws, N, T);
   tps_assemble_kernel<<<dim3(ceil_div(n, 16), ceil_div(n, 16), N), 256, 0, s>>>(ctrl, lmbda, w, f.A, T, f.lda,
                                                                              f.a_stride);
-  int rc;
-  if (n <= 600) rc = launch_lu<16>(f, N, n, s);
-  else if (n <= 1150) rc = launch_lu<8>(f, N, n, s);
+  int rc, clustered = 0;
+  if (n <= 600) rc = launch_lu<16>(f, N, n, s, &clustered);
+  else if (n <= 1150) rc = launch_lu<8>(f, N, n, s, &clustered);
   else return -22;
   if (rc) return rc;
+  if (clustered) {
+    int forced = g_force_retry.load(std::memory_order_relaxed);
+    if (forced > 0 && g_force_retry.compare_exchange_strong(forced, forced - 1))
+      tps_mark_retry_kernel<<<ceil_div(N, 64), 64, 0, s>>>(f.info, N);
+    rc = n <= 600 ? launch_lu_retry<16>(f, ctrl, lmbda, w, N, T, s) : launch_lu_retry<8>(f, ctrl, lmbda, w, N, T, s);
+    if (rc) return rc;
+  }
   tps_solve_kernel<<<N, LU_TPB, solve_lds(n), s>>>(f.A, f.ipiv, tgt, T, theta, nullptr, n, f.lda, f.a_stride, f.info);
   return KMH_LAUNCH_CHECK();
 }

@@ -1471,20 +1471,33 @@ KMH_API int kmh_dice_sums(const float* pred, const float* target, int R, long lo
  * written.  Replaces keymorph/utils.py:14-21 followed by the three reductions of keymorph/loss_ops.py:28-52 (caller
  * scripts/train.py:146-164).  ws: kmh_reduce_ws_bytes().  Returns KMH_EINVAL (-22) when the lane-contiguous kernel does
  * not apply (W < 2, a plane of >= 2^31 voxels, C > 128): the caller then uses the separate entry points. */
+/* The ONE statement of when the fused warp + Dice kernels apply (both entry points return -22 otherwise, and
+ * kmh_warp_dice_ok lets the host decide BEFORE it builds an autograd node: the unfused composition align_img + DiceLoss is
+ * the documented fallback): the lane-contiguous sampler (W >= 2, not switched off by KMH_SAMPLER_OLD), < 2^30 voxels per
+ * channel plane (32-bit byte offsets), <= 128 channels (the sums' LDS table), and N * C rows whose block partials --
+ * (N, nb, C, 3) doubles with nb >= 1 -- fit the reduction workspace. */
+static bool warp_dice_supported(int N, int C, int D, int H, int W) {
+  return N > 0 && C > 0 && C <= WD_MAXC && lane_contiguous_ok(D, H, W) && (long long)D * H * W < (1ll << 30) &&
+         (long long)N * C <= 65536;
+}
+KMH_API int kmh_warp_dice_ok(int N, int C, int D, int H, int W) { return warp_dice_supported(N, C, D, H, W) ? 1 : 0; }
+
 KMH_API int kmh_warp_dice_sums(const float* x, const float* grid, const float* fixed, float* sums, int N, int C, int D,
                                int H, int W, int Do, int Ho, int Wo, const unsigned char* lab_x,
                                const unsigned char* lab_fixed, const int* gate, void* ws, void* stream) {
-  if (N <= 0 || C <= 0 || C > WD_MAXC || !lane_contiguous_ok(D, H, W) || (long long)D * H * W >= (1ll << 30)) return -22;
+  if (!warp_dice_supported(N, C, D, H, W)) return -22;
   const bool labs = lab_x && lab_fixed && gate;
   if (!labs && (lab_x || lab_fixed || gate)) return -22;            // all three or none
   const long long ovox = (long long)Do * Ho * Wo;
   const int nchunk = ceil_div(ovox, (long long)TPB * PASSES);
-  long long nb = 65536 / ((long long)N * C);          // partial (N, nb, C, 3) doubles inside the reduction workspace
-  if (nb < 1) return -22;
+  const long long nb_cap = 65536 / ((long long)N * C);   // partial (N, nb, C, 3) doubles inside the reduction workspace
+  long long nb = nb_cap;                                 // (>= 1: warp_dice_supported)
   if (nb > nchunk) nb = nchunk;
   static const int capa = getenv("KMH_WD_BLOCKS") ? atoi(getenv("KMH_WD_BLOCKS")) : 768;   // ~ resident blocks of the chip
   const int per_n = (capa / N) & ~7;                 // a multiple of 8 per sample row: blockIdx.x % 8 is the XCD
   if (nb > per_n) nb = per_n < 8 ? 8 : per_n;
+  if (nb > nb_cap) nb = nb_cap;                      // (per_n < 8 rounds UP to 8: never past the workspace)
+  if (nb < 1) nb = 1;
   hipStream_t s = (hipStream_t)stream;
   static const int ilp = getenv("KMH_WD_ILP_A") ? atoi(getenv("KMH_WD_ILP_A")) : 4;        // A/B switch (tools/bench_warp_dice.py)
   const dim3 g((unsigned)nb, N);
@@ -1523,7 +1536,7 @@ KMH_API int kmh_onehot_to_labels(const float* x, int N, int C, long long V, unsi
 KMH_API int kmh_warp_dice_bwd_grid(const float* x, const float* grid, const float* fixed, const float* ca, const float* cb,
                                    float* dgrid, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
                                    const unsigned char* lab_x, const unsigned char* lab_fixed, const int* gate, void* stream) {
-  if (N <= 0 || C <= 0 || !lane_contiguous_ok(D, H, W) || (long long)D * H * W >= (1ll << 30)) return -22;
+  if (!warp_dice_supported(N, C, D, H, W)) return -22;
   const bool labs = lab_x && lab_fixed && gate;
   if (!labs && (lab_x || lab_fixed || gate)) return -22;
   const long long ovox = (long long)Do * Ho * Wo;

@@ -92,15 +92,21 @@ class KeyMorph(nn.Module):
 
     def _tps_lmbda_on(self, num_samples, tps_lmbda, device):
         """_convert_tps_lmbda(...).to(device).float(); a FIXED lambda is created on the device once per (value, count) -- the
-        host-to-device copy of a fresh CPU tensor is a blocking point in every step otherwise"""
+        host-to-device copy of a fresh CPU tensor is a blocking point in every step otherwise.  Callers get a device-side
+        CLONE of the cached tensor (no host synchronisation): an in-place edit downstream cannot corrupt later steps, and
+        the clone is an ordinary tensor even when the cache entry was first created under `torch.inference_mode()` (an
+        inference tensor cannot be saved for a later backward).  dtype: float32 always (the reference passes float64 for
+        the random-lambda strings and casts inside `TPS.fit`)."""
         if isinstance(tps_lmbda, str):
+            return self._convert_tps_lmbda(num_samples, tps_lmbda).to(device).float()
+        if torch.is_inference_mode_enabled():      # (nothing created here may enter the cache)
             return self._convert_tps_lmbda(num_samples, tps_lmbda).to(device).float()
         cache = self.__dict__.setdefault("_lmbda_cache", {})
         key = (float(tps_lmbda), int(num_samples), str(device))
         t = cache.get(key)
         if t is None:
             t = cache[key] = self._convert_tps_lmbda(num_samples, tps_lmbda).to(device).float()
-        return t
+        return t.clone()
 
     @staticmethod
     def is_supported_transform_type(s):

@@ -293,10 +293,14 @@ class _WarpDiceRows(torch.autograd.Function):
 
 
 def warp_dice_ok(x: Tensor, grid: Tensor) -> bool:
-    """does the fused warp + Dice pass apply?  (5-D, bilinear lane-contiguous sampler with 32-bit byte offsets: W >= 2,
-    < 2^30 voxels per channel plane, <= 128 channels; the grid is the only input that needs a gradient)"""
-    return (x.dim() == 5 and grid.dim() == 5 and x.shape[4] >= 2 and x.shape[2] * x.shape[3] * x.shape[4] < 2 ** 30
-            and x.shape[1] <= 128 and not x.requires_grad)
+    """does the fused warp + Dice pass apply?  The size conditions are the library's own (`kmh_warp_dice_ok`, the same
+    predicate its two entry points return -22 on: W >= 2, < 2^30 voxels per channel plane, <= 128 channels, N * C <= 65536
+    rows, the lane-contiguous sampler not switched off by KMH_SAMPLER_OLD); on top of them the grid must be the only input
+    that needs a gradient (`fixed.requires_grad` is the caller's check: loss_ops.warp_dice_loss)."""
+    if not (x.dim() == 5 and grid.dim() == 5 and not x.requires_grad):
+        return False
+    N, C, D, H, W = (int(v) for v in x.shape)
+    return bool(_lib.load().kmh_warp_dice_ok(N, C, D, H, W))
 
 
 def warp_dice_rows(x: Tensor, grid: Tensor, fixed: Tensor) -> Tensor:

@@ -316,6 +316,37 @@ def test_convnet_lazy_instance_norm_equals_block_by_block(shape, N, monkeypatch)
         assert float((a - r).norm() / (r.norm() + 1e-30)) < 3e-2, (k, "lazy vs oracle")
 
 
+def test_convnet_instance_image_gradient_when_the_input_requires_it():
+    """An image that requires a gradient (saliency / adversarial use) gets it through ConvNet(instance): the fused lazy
+    units never form d/d(image), so such an input must take the block-by-block route -- against the oracle's autograd."""
+    from keymorph_amd import backbone_ops as B
+    from keymorph_amd.net import ConvNet
+    from oracle import keymorph_oracle as O
+    from tests.util import convnet_shapes
+    shapes = convnet_shapes(8)
+    sd = seeded_state_dict(shapes, 103)
+    x = torch.rand((1, 1, 32, 32, 32), generator=gen(12))
+    net = ConvNet(3, 1, 8, "instance")
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).train()
+    xh = x.to(DEV).requires_grad_(True)
+    before = B.LAZY_IN_STATS["units"]
+    y = net(xh)
+    assert B.LAZY_IN_STATS["units"] == before, "the lazy units ran although the image requires a gradient"
+    cot = torch.linspace(-1, 1, y.numel(), device=DEV).reshape(y.shape)
+    (y * cot).sum().backward()
+    assert xh.grad is not None
+    xr = x.clone().requires_grad_(True)
+    yr = O.convnet_forward({k: v.clone() for k, v in sd.items()}, xr, "instance")
+    (yr * cot.cpu()).sum().backward()
+    e = float((xh.grad.cpu().double() - xr.grad.double()).norm() / (xr.grad.double().norm() + 1e-30))
+    assert e < 3e-2, e
+    # and without the requirement the lazy units are back
+    y2 = net(x.to(DEV))
+    assert B.LAZY_IN_STATS["units"] - before == 9
+    close(y2, y.detach(), 2e-5 * max(1.0, float(y.abs().max())), 1e-4)
+
+
 def test_convnet_instance_128_vs_oracle_forward_and_autograd():
     """The reference's other backbone at a size its blocks are not toys (keymorph/net.py:7-36; 128^3, 64 keypoints, the
     lazy-InstanceNorm route): keypoint logits and center-of-mass keypoints against the oracle, and every weight gradient of

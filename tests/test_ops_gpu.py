@@ -240,6 +240,44 @@ def test_fused_warp_dice_falls_back_when_the_moving_segmentation_needs_a_gradien
     assert seg_m.grad is not None and grid.grad is not None
 
 
+def test_fused_warp_dice_predicate_is_the_kernels_own_and_the_fallback_is_taken():
+    """`ops.warp_dice_ok` is the library's predicate (the one its entry points return -22 on), so a shape the fused kernels do
+    not serve -- > 128 channels; N * C beyond the partial-sum workspace, where the block count used to be rounded UP past
+    it -- falls back to align_img + DiceLoss instead of raising; a many-row shape that IS served agrees with the fallback."""
+    from keymorph_amd import _lib, loss_ops, ops as kops
+    from keymorph_amd.utils import align_img
+    lib = _lib.load()
+    assert lib.kmh_warp_dice_ok(2, 14, 256, 256, 256) == 1
+    assert lib.kmh_warp_dice_ok(1, 129, 8, 8, 8) == 0            # channels
+    assert lib.kmh_warp_dice_ok(1, 4, 8, 8, 1) == 0              # W < 2
+    assert lib.kmh_warp_dice_ok(1024, 128, 4, 4, 4) == 0         # N * C > 65536 rows
+    assert lib.kmh_warp_dice_ok(512, 128, 4, 4, 4) == 1
+    g = gen(10)
+    # C = 130: not served -> the documented composition, with a gradient
+    seg_m = torch.rand(1, 130, 4, 4, 4, generator=g).to(DEV)
+    seg_f = torch.rand(1, 130, 4, 4, 4, generator=g).to(DEV)
+    grid = (O.base_grid((4, 4, 4)).flip(-1)[None] * 0.9).to(DEV).requires_grad_(True)
+    assert not kops.warp_dice_ok(seg_m, grid)
+    loss = loss_ops.warp_dice_loss(grid, seg_m, seg_f)
+    loss.backward()
+    ref = loss_ops.DiceLoss()(align_img(grid.detach(), seg_m), seg_f)
+    close(loss.detach(), ref, 1e-6)
+    assert grid.grad is not None and torch.isfinite(grid.grad).all()
+    # N = 100 (> 96: per-sample block count 0 before the fix), C = 100: N * C = 10000 rows, workspace cap 6 blocks per row
+    N, C = 100, 100
+    seg_m = torch.rand(N, C, 4, 4, 6, generator=g).to(DEV)
+    seg_f = torch.rand(N, C, 4, 4, 6, generator=g).to(DEV)
+    grid = (O.base_grid((4, 4, 6)).flip(-1)[None] * 0.9).repeat(N, 1, 1, 1, 1).to(DEV).requires_grad_(True)
+    assert kops.warp_dice_ok(seg_m, grid)
+    fused = loss_ops.warp_dice_loss(grid, seg_m, seg_f)
+    fused.backward()
+    g2 = grid.detach().clone().requires_grad_(True)
+    unfused = loss_ops.DiceLoss()(align_img(g2, seg_m), seg_f)
+    unfused.backward()
+    close(fused.detach(), unfused.detach(), 1e-6)
+    close(grid.grad, g2.grad, 1e-7 + 1e-4 * float(g2.grad.abs().max()))
+
+
 # ---------------------------------------------------------------- grids
 @pytest.mark.parametrize("shape", [(6, 7, 8), (16, 16, 16), (5, 9, 13)])
 def test_affine_grid(shape):
@@ -366,8 +404,9 @@ def test_tps_fit_vs_fp64(T_, lam):
     close(out, ref, 5e-3 * scale if lam == 0.0 else 2e-4 * scale, 1e-3)
 
 
-@pytest.mark.parametrize("T_,lam", [(16, 0.5), (100, 1.0)])
+@pytest.mark.parametrize("T_,lam", [(16, 0.5), (100, 1.0), (512, 1.0), (512, 0.05)])
 def test_tps_fit_bwd(T_, lam):
+    """dctrl, dtgt against the fp64 oracle's autograd; T = 512 runs the workgroup-cluster factorisation the headline uses."""
     g = gen(40 + T_)
     ctrl = torch.rand(2, T_, 3, generator=g) * 1.6 - 0.8
     tgt = ctrl + 0.05 * torch.randn(2, T_, 3, generator=g)
@@ -377,6 +416,39 @@ def test_tps_fit_bwd(T_, lam):
     (O.tps_fit(cr, tr, lm.double()) * cot.double()).sum().backward()
     ch, th = ctrl.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
     (ops().tps_fit(ch, th, lm.to(DEV)) * cot.to(DEV)).sum().backward()
+    close(th.grad, tr.grad.float(), 1e-3 * float(tr.grad.abs().max()), 1e-3)
+    close(ch.grad, cr.grad.float(), 1e-3 * float(cr.grad.abs().max()), 1e-3)
+
+
+def test_tps_fit_cluster_retry_pass_equals_one_workgroup_result():
+    """A cluster factorisation that gives up (bounded waits: its workgroups were not all resident) is redone on the
+    one-workgroup kernel inside the same call.  The test hook marks every system as "gave up": the retry pass then does all
+    the work, and theta / the backward's factors must equal the fp64 solve like the normal path's do (never NaN)."""
+    from keymorph_amd import _lib
+    g = gen(77)
+    T_ = 512
+    ctrl = torch.rand(2, T_, 3, generator=g) * 1.6 - 0.8
+    tgt = ctrl + 0.05 * torch.randn(2, T_, 3, generator=g)
+    lm = torch.full((2,), 1.0)
+    cot = torch.randn(2, T_ + 4, 3, generator=g)
+    ref = O.tps_fit(ctrl.double(), tgt.double(), lm.double())
+    normal = ops().tps_fit(ctrl.to(DEV), tgt.to(DEV), lm.to(DEV))
+    prev = _lib.load().kmh_tps_fit_force_retry(1)
+    try:
+        ch, th = ctrl.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        retried = ops().tps_fit(ch, th, lm.to(DEV))
+        (retried * cot.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        left = _lib.load().kmh_tps_fit_force_retry(0)
+    finally:
+        _lib.load().kmh_tps_fit_force_retry(prev)
+    assert left == 0, "the forced-retry credit was not consumed: the cluster path did not run for T = 512"
+    assert torch.isfinite(retried).all()
+    scale = float(ref.abs().max())
+    close(retried, ref.float(), 2e-4 * scale, 1e-3)
+    close(retried, normal, 1e-5 * scale, 1e-5)      # two fp64 factorisations of one matrix (pivot order may differ)
+    cr, tr = ctrl.double().requires_grad_(True), tgt.double().requires_grad_(True)
+    (O.tps_fit(cr, tr, lm.double()) * cot.double()).sum().backward()
     close(th.grad, tr.grad.float(), 1e-3 * float(tr.grad.abs().max()), 1e-3)
     close(ch.grad, cr.grad.float(), 1e-3 * float(cr.grad.abs().max()), 1e-3)
 
