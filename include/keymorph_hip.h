@@ -203,6 +203,14 @@ int kmh_conv3d_fwd_bf(const float* x, const float* scale, const float* shift, co
  * 2: conv3_fwd_g_kernel whenever its preconditions hold (parity tests on small / ragged volumes).  Returns the
  * previous mode, -22 for a bad argument. */
 int kmh_conv3d_fwd_bf_set_dispatch(int mode);
+/* in_blocked of kmh_conv3d_fwd_bf: 0 = x is (N,D,H,W,Cin); 1 = channel-blocked (N,Cin/8,D,H,W,8) fp32; 2 = PRE-SPLIT
+ * channel-blocked: (N, Cin/8, D*H*W + 1) records of 32 bytes, the 8 fp16 "hi" then the 8 fp16 "lo" terms of fmaf(value, S, 0)
+ * with S = ascale[0], record D*H*W of every plane zero -- what kmh_maxpool3d_bwd_split writes; the kernel then copies
+ * fragments (LDS-DMA) instead of converting them, with bit-identical results (conv3_fwd_s_kernel<1,true,true>).  Mode 2 serves
+ * gradient operands (no scale / shift / mask / relu_in / addend) of the z-paired tile (Cout <= 16): kmh_conv3d_fwd_bf_split_ok
+ * returns 1 for the shapes it takes, kmh_conv3d_fwd_bf returns -22 for the others.  Replaces the data gradient of
+ * keymorph/unet3d/buildingblocks.py:46-58 (autograd of conv3d) behind a pooling layer (:321-380). */
+int kmh_conv3d_fwd_bf_split_ok(int N, int D, int H, int W, int Cin, int Cout, int terms);
 /* the kernel kmh_conv3d_fwd_bf would launch for this call now: 0 conv3_fwd_bf_kernel, 1 / 2 conv3_fwd_g_kernel with a
  * 32- / 64-wide output-channel tile, 3 its z-paired variant (Cout <= 16) */
 int kmh_conv3d_fwd_bf_variant(int N, int D, int H, int W, int Cin, int Cout, int terms, int has_mask, int has_addend);
@@ -348,6 +356,12 @@ int kmh_maxpool3d_fwd(const float* x, float* y, unsigned char* argmax, int N, in
  * (U-Net skip connection; may alias dx).  Odd D/H/W: the caller pre-fills the window-less trailing planes. */
 int kmh_maxpool3d_bwd(const float* x, const unsigned char* argmax, const float* dy, const float* add, int add_cstride,
                       float* dx, int N, int D, int H, int W, int C, int out_blocked, void* stream);
+/* MaxPool3d(2)'s backward written PRE-SPLIT for kmh_conv3d_fwd_bf(in_blocked = 2): dxs is (N, C/8, D*H*W + 1) records of 32
+ * bytes (kmh_maxpool3d_bwd_split_bytes), dy_scale2 = {S, 1/S} the range scale of dy (a scatter keeps it); even D, H, W,
+ * C % 8 == 0; autograd of max_pool3d (keymorph/unet3d/buildingblocks.py:321-380) in the consumer's operand format. */
+size_t kmh_maxpool3d_bwd_split_bytes(int N, int D, int H, int W, int C);
+int kmh_maxpool3d_bwd_split(const unsigned char* argmax, const float* dy, const float* dy_scale2, float* dxs, int N, int D,
+                            int H, int W, int C, void* stream);
 /* dx = scatter(dy) + [x > 0] (c1 dxn + c2 x + c3): the pooling backward summed with the skip connection's gradient whose
  * GroupNorm backward (c123 (N,C,3), kmh_gn_bwd_apply's coefficients) is applied on the fly -- autograd of max_pool3d plus
  * the decoder's skip (keymorph/unet3d/buildingblocks.py:363, 471-475) in one pass; even D, H, W, C % 4 == 0, dense

@@ -69,6 +69,7 @@ PROTOS = {
     "kmh_conv3d_fwd_bf_set_dispatch": (_i, [_i]),
     "kmh_conv3d_fwd_bf_variant": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "kmh_conv3d_fwd_bf_pool_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "kmh_conv3d_fwd_bf_split_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "kmh_conv3d_fwd_bf_pool": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f]),
     "kmh_conv3d_up2_dgrad_pack_bytes": (_sz, [_i, _i, _i]),
     "kmh_conv3d_up2_dgrad_pack_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f]),
@@ -105,6 +106,8 @@ PROTOS = {
     "kmh_norm_apply": (_i, [_f, _f, _f, _i, _ll, _i, _i, _f, _f]),
     "kmh_maxpool3d_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "kmh_maxpool3d_bwd": (_i, [_f, _f, _f, _f, _i, _f, _i, _i, _i, _i, _i, _i, _f]),
+    "kmh_maxpool3d_bwd_split_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "kmh_maxpool3d_bwd_split": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "kmh_maxpool3d_bwd_lazy": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f]),
     "kmh_upcat_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f]),
     "kmh_upcat_bwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f]),

@@ -361,6 +361,19 @@ def grad_blocked_ok(N, D, H, W, Cin, Cout) -> bool:
 
 
 BLOCKED_STATS = {"handoffs": 0}      # channel-blocked gradient hand-offs performed (tests)
+SPLIT_STATS = {"handoffs": 0}        # pooled gradients scattered straight into pre-split fp16 records (tests)
+
+
+def pool_grad_split_ok(N, D, H, W, Cin, Cout) -> bool:
+    """May the backward of a (Cin -> Cout) conv + pooling operator scatter the pooled gradient straight into the pre-split
+    records (`kmh_maxpool3d_bwd_split`)?  Both consumers must take them: the data gradient (Cout -> Cin, the z-paired tile of
+    the one-wave kernel: `kmh_conv3d_fwd_bf_split_ok`) and the wave-specialised weight gradient.  KEYMORPH_NO_SPLIT_POOLGRAD=1
+    keeps the fp32 scatter (A/B runs, tests)."""
+    if CONV_MODE != "f16x3" or os.environ.get("KEYMORPH_NO_SPLIT_POOLGRAD") or Cout % 8:
+        return False
+    lib = _lib.load()
+    return bool(lib.kmh_conv3d_fwd_bf_split_ok(N, D, H, W, Cout, Cin, 2)) and \
+        bool(lib.kmh_conv3d_wgrad_bf_blocked_ok(N, D, H, W, Cin, Cout, 2))
 
 
 def _is_blocked(t) -> bool:
@@ -467,15 +480,28 @@ class _SingleConvGCR(torch.autograd.Function):
             raise RuntimeError("keymorph_amd: the first encoder block's lazy GroupNorm-backward hand-off lost its tag (a "
                                "hook replaced the gradient?) -- set KEYMORPH_NO_LAZY_FIRST=1")
         dy = _prep(dy)
+        dy_split = False
         if ctx.pool:
             # the pooled output's gradient -> the full-resolution one through the winners recorded by the epilogue
             # (the pooling layer's backward, kmh_maxpool3d_bwd), channel-blocked when the gradient kernels take it so
-            full = torch.empty((N, D, H, W, Cout), dtype=torch.float32, device=dy.device)
             odd = (D | H | W) & 1
-            if odd:
-                full.zero_()
-            check(lib.kmh_maxpool3d_bwd(None, _p(ctx.pool_arg), _p(dy), None, 0, _p(full), N, D, H, W, Cout,
-                                        int(dy_blocked), _stream()), "kmh_maxpool3d_bwd")
+            dy_split = (dy_blocked and not odd and _needs_range_scales() and pool_grad_split_ok(N, D, H, W, Cin, Cout)
+                        and not (Cin == 1 and not ctx.needs_input_grad[0]))
+            if dy_split:
+                # ... and PRE-SPLIT into the fp16 hi / lo records both gradient kernels multiply with: a scatter keeps the
+                # range scale of the pooled gradient, so the split can be done by the pass that writes the tensor and the
+                # z-paired data gradient copies fragments instead of converting them (kmh_maxpool3d_bwd_split)
+                sd_in = sd_in if sd_in is not None else absmax_scale(dy)
+                full = torch.empty((N, Cout // 8, D * H * W + 1, 8), dtype=torch.float32, device=dy.device)
+                check(lib.kmh_maxpool3d_bwd_split(_p(ctx.pool_arg), _p(dy), _p(sd_in), _p(full), N, D, H, W, Cout, _stream()),
+                      "kmh_maxpool3d_bwd_split")
+                SPLIT_STATS["handoffs"] += 1
+            else:
+                full = torch.empty((N, D, H, W, Cout), dtype=torch.float32, device=dy.device)
+                if odd:
+                    full.zero_()
+                check(lib.kmh_maxpool3d_bwd(None, _p(ctx.pool_arg), _p(dy), None, 0, _p(full), N, D, H, W, Cout,
+                                            int(dy_blocked), _stream()), "kmh_maxpool3d_bwd")
             _tag_grad_scale(full, sd_in)       # scattering moves values: the bound of the pooled gradient holds
             dy = full
             if dy_blocked:
@@ -504,14 +530,14 @@ class _SingleConvGCR(torch.autograd.Function):
         fold = need_dxn and ctx.needs_input_grad[3] and conv_emits_stats() and not os.environ.get("KEYMORPH_NO_STATS_FOLD")
         bhat = torch.zeros((N, Cin), dtype=torch.float64, device=x.device) if fold else None
         dw = (conv3_wgrad(x, scale, shift, dy, N, D, H, W, Cin, Cout, False, dzmask=ymask, xscale=ctx.ascale,
-                          dscale=dscale, dz_blocked=dy_blocked, fold=(weight, bhat) if fold else None)
+                          dscale=dscale, dz_blocked=2 if dy_split else dy_blocked, fold=(weight, bhat) if fold else None)
               if ctx.needs_input_grad[3] else None)
         dx = dgamma = dbeta = None
         if need_dxn:
             dstats = torch.empty((N, Cin, 2), dtype=torch.float64, device=x.device) if fold else None
             dxn = conv3_raw(dy, None, None, pack_weight(weight, True, getattr(ctx, "wscale", None)), None, N, D, H, W,
                             Cout, Cin, False, False,
-                            mask=ymask, ascale=dscale, in_blocked=dy_blocked, stats_out=dstats)
+                            mask=ymask, ascale=dscale, in_blocked=2 if dy_split else dy_blocked, stats_out=dstats)
             c123 = _f32((N, Cin, 3), x.device)
             sc2 = (torch.zeros(2, dtype=torch.float32, device=x.device)
                    if (_needs_range_scales() and ctx.needs_input_grad[0]) else None)

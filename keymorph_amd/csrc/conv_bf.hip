@@ -910,11 +910,25 @@ static_assert(GPL <= S_PLANE && GTZ == 4 && GTY == S_MR, "wave = plane, 8 rows")
 #ifndef KMH_S_ADB
 #define KMH_S_ADB 1
 #endif
+#ifndef KMH_SP_BA
+#define KMH_SP_BA 9
+#endif
+#ifndef KMH_SP_PSTEPS
+#define KMH_SP_PSTEPS 5
+#endif
 
 // ZP (Cout <= 16, z-paired weights, NT = 1): wave = (plane pair, row half) -- 4 rows, the N tile is (16 couts x 2 planes) over the
 // pair's 4-plane input window, 18 tap-pair steps of 12 MFMAs (the eight-wave kernel: 6 per wave and step, the most
 // overhead-bound launch of the step).
-template <int NT, bool ZP = false>
+// SPLIT (round 5): the input arrives ALREADY range-scaled and split -- x is (N, Cin/8, V + 1) records of 32 bytes, 8 fp16 hi
+// then 8 fp16 lo of one voxel's chunk, record V of every (sample, chunk) plane all zeros (the source of every padding slot) --
+// written so by its producer (kmh_maxpool3d_bwd_split: a pooling backward knows its output's range scale before it writes).
+// A stage's fragment images are then 16 LDS-DMA pieces per lane (global_load_lds_dwordx4, hi -> plane 0, lo -> plane 1), one
+// or two per step, and NO conversion: no staging registers, no VALU, no coefficient table.  What that buys where the
+// conversion cannot hide: the z-paired 32 -> 16 data gradient at 256^3 has 18 x 12 MFMAs per chunk (6.9k cycles) against a
+// conversion of the same length (cycle stamps, profiles/r5a): 1300-1800 cycles per conversion step against 384 of MFMA time.
+// Bit-identical to the fp32 input: the producer applies the same fmaf(x, S, 0) and split8<2>.
+template <int NT, bool ZP = false, bool SPLIT = false>
 __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16x8* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int D, int H, int W, int Cin,
@@ -960,14 +974,30 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   const int wz = ZP ? 2 * (wv >> 1) : wv, wy = ZP ? (wv & 1) * MR : 0;      // first output plane / row of the wave
   const int vrow = (wz * GHY + wy) * HX + li;
   const long long vox = (long long)D * H * W;
-  const long long chunk_stride = in_blocked ? vox * KC : KC;
-  auto sample_base = [&](int n) { return in_blocked ? x + (long long)n * nchunk * vox * KC : x + (long long)n * vox * Cin; };
+  const long long plane = SPLIT ? (vox + 1) * KC : vox * KC;      // floats per (sample, chunk) plane of a channel-blocked input
+  const long long chunk_stride = (in_blocked || SPLIT) ? plane : KC;
+  auto sample_base = [&](int n) {
+    return (in_blocked || SPLIT) ? x + (long long)n * nchunk * plane : x + (long long)n * vox * Cin;
+  };
 
   // LDS-DMA descriptors of a brick: 16-byte slot e = r * 256 + tid holds half (r >> 3) of halo voxel (r & 7) * 256 + tid
   auto fill_offsets = [&](const Item& it) {
     const int x0 = it.bx * TX, y0 = it.by * GTY, z0 = it.bz * GTZ;
     int t_ = tid;
     asm volatile("" : "+v"(t_));
+    if constexpr (SPLIT) {
+      // one record offset (floats) per halo voxel of this lane: slot r * 256 + tid; padding voxels and the 8 slots past the
+      // halo point at the plane's zero record
+#pragma unroll
+      for (int r = 0; r < S_NCV; ++r) {
+        const int v = r * S_TPB + t_;
+        const int lx = v % HX, ly = (v / HX) % GHY, lz = v / (HX * GHY);
+        const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - 1;
+        const bool in = (v < GPL) && ((unsigned)gx < (unsigned)W) && ((unsigned)gy < (unsigned)H) && ((unsigned)gz < (unsigned)D);
+        sOff[r * S_TPB + t_] = in ? ((gz * H + gy) * W + gx) * KC : (int)vox * KC;      // read back by this thread only
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < S_NLD; ++r) {
       const int e = r * S_TPB + t_, v0_ = (r & 7) * S_TPB + t_, v = v0_ < GPL ? v0_ : GPL - 1;
@@ -1041,14 +1071,29 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     for (int t = 0; t < TERMS; ++t) B8[t * S_PLANE + v] = parts[t];
   };
 
+  // SPLIT: piece p (0..15) of a stage = plane (p & 1) of the lane's voxel p >> 1: 16 bytes per lane straight into the
+  // fragment image of stage buffer `buf` (wave-uniform LDS base + 16 x lane), source = the voxel's record (+ 16 bytes for lo)
+  auto dma_piece = [&](int n, int ch, int buf, int p, int off) {
+    const float* src = sample_base(n) + ch * chunk_stride + off + 4 * (p & 1);
+    unsigned char* dst = gsm + buf * S_BUF_BYTES + ((p & 1) * S_PLANE + (p >> 1) * S_TPB + wv * 64) * 16;
+    __builtin_amdgcn_global_load_lds((kmh_glb_ptr)src, (kmh_lds_ptr)dst, 16, 0, 0);
+  };
   // B fragments straight from L2 through a two-slot register ring that runs THROUGH the stage boundaries: the fragments of step
   // s + 1 are requested at the HEAD of step s (into the slot step s - 1 has just finished issuing from), so they have a whole
   // step -- ~1.5k cycles, several L2 round trips -- to land, and every step opens with a plain `s_waitcnt vmcnt(0)`: no counted
   // waits.  (Counted waits -- vmcnt(number of younger loads), the scheme of conv3_fwd_g_kernel -- gave run-to-run different
   // results here in the steps that carry no other drain, with strict counts too; the root cause was not found, the full drain
   // costs nothing once the loads are issued a step ahead.)
-  constexpr int BD = KMH_S_BD;
-  static_assert(BD == 2 && NST % BD == 0, "the ring slot of a step must not depend on the stage");
+  // SPLIT: the ring holds a whole stage's fragments (one slot per step) and the fragments of step s + BA are requested in step
+  // s, so that the wave drains its memory queue only at the head of every BA-th step: the LDS-DMA pieces of the next stage's
+  // halo, issued in the steps right after a drain, then have BA - SP_PS + 1 or more steps (thousands of cycles) to come in
+  // from HBM before anything waits for them -- a drain at every step head would expose that latency 18 times per chunk.
+  constexpr int BD = SPLIT ? NST : KMH_S_BD;             // ring slots
+  constexpr int BA = SPLIT ? KMH_SP_BA : 1;              // request distance = drain period (steps)
+  constexpr int SP_PS = KMH_SP_PSTEPS;                   // SPLIT: the stage's 16 DMA pieces go out in steps 0 .. SP_PS - 1
+  static_assert(NST % BD == 0 && (SPLIT || BD == 2), "the ring slot of a step must not depend on the stage");
+  static_assert(!SPLIT || (NST % BA == 0 && SP_PS < BA && NT == 1), "drains at steps 0, BA, ...; pieces land before the next one");
+  auto piece_beg = [](int s) -> int { return s >= SP_PS ? S_NLD : (S_NLD * s) / SP_PS; };      // pieces of steps 0 .. SP_PS - 1
   constexpr int BL = 2 * NT;
   const long long step_stride = 2ll * CoutP, term_stride = (long long)NST * step_stride;
   bf16x8 bq[BD][NT][TERMS];
@@ -1078,17 +1123,26 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   };
   // prologue: the first stage's halo, fetched and converted with nothing to hide behind
   fill_offsets(cur);
-  unsigned cv_in = inside_bits(cur);
-  fill_coef(cur.n);
-  __syncthreads();
+  unsigned cv_in = 0u;
+  if constexpr (SPLIT) {
 #pragma unroll
-  for (int i = 0; i < S_NCV; ++i) {
-    raw_issue(cur.n, 0, 0, sOff[i * S_TPB + tid], sOff[(8 + i) * S_TPB + tid]);
+    for (int p = 0; p < S_NLD; ++p) dma_piece(cur.n, 0, 0, p, sOff[(p >> 1) * S_TPB + tid]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    convert1(0, cv_in, 0, i, rawq[0][0], rawq[0][1]);
+  } else {
+    cv_in = inside_bits(cur);
+    fill_coef(cur.n);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < S_NCV; ++i) {
+      raw_issue(cur.n, 0, 0, sOff[i * S_TPB + tid], sOff[(8 + i) * S_TPB + tid]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      convert1(0, cv_in, 0, i, rawq[0][0], rawq[0][1]);
+    }
   }
-  o0 = lh * CoutP + cur.cog * (32 * NT) + li;             // chunk 0 of the first brick: step 0's fragments
-  b_issue(0);
+  o0 = lh * CoutP + cur.cog * (32 * NT) + li;             // chunk 0 of the first brick: the fragments of steps 0 .. BA - 1
+#pragma unroll
+  for (int d = 0; d < BA; ++d) b_issue(d);
+  if (SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int pb = 0;                                              // stage buffer holding the CURRENT stage's fragment images
   for (;;) {
     const bool more = next_item(vb, nxt);
@@ -1115,7 +1169,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
       const bool have_next = !last_ch || more;
       const int nn = (last_ch && more) ? nxt.n : n, nch = last_ch ? 0 : ch + 1;      // (no next stage: any valid pair)
       unsigned cv_next = last_ch ? 0u : cv_in;             // (the next BRICK's table and bits: inside step 0, below)
-      if (nn != coef_n) {                                  // uniform, rare: the work list moves on to another sample
+      if (!SPLIT && nn != coef_n) {                        // uniform, rare: the work list moves on to another sample
         fill_coef(nn);
         __syncthreads();
       }
@@ -1135,19 +1189,29 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
       for (int s = 0; s < NST; ++s) {
         // everything requested so far has landed: this step's B fragments (requested at the head of the last step), the raw
         // voxel s - 1, a previous brick's output stores
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (s + 1 < NST) b_issue((s + 1) % BD);               // the next step's fragments ...
-        else if (have_next) {                                 // ... or step 0's of the next stage
-          o0 = (long long)nch * TERMS * term_stride + lh * CoutP + co0n + li;
-          b_issue(0);
+        // (SPLIT: only every BA-th step drains; step 0 of a brick's first stage does not either -- its fragments were waited
+        // for ahead of the previous brick's epilogue, whose output stores thus stay in flight under BA steps of MFMAs)
+        if (!SPLIT || (s % BA == 0 && !(s == 0 && ch == 0))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (s + BA < NST) b_issue((s + BA) % BD);             // the fragments of step s + BA ...
+        else if (have_next) {                                 // ... or of step s + BA - NST of the next stage
+          if (s + BA == NST) o0 = (long long)nch * TERMS * term_stride + lh * CoutP + co0n + li;
+          b_issue((s + BA - NST) % BD);
         }
         __builtin_amdgcn_sched_barrier(0);
         // the next stage's voxel s - 1 is requested in step s (1..8) and converted in step s + 1.  Step 0 of a brick's last stage
         // first replaces the offset table and the inside bits by the next brick's (~400 VALU: fillers here, 3k cycles at the
         // stage top before)
-        if (s == 0 && last_ch && more) { fill_offsets(nxt); cv_next = inside_bits(nxt); }
+        if (s == 0 && last_ch && more) { fill_offsets(nxt); if (!SPLIT) cv_next = inside_bits(nxt); }
+        if constexpr (SPLIT) {
+          // this step's share of the next stage's 16 pieces (step 0: after the offset table has been replaced)
+          if (have_next) {
+#pragma unroll
+            for (int p = piece_beg(s); p < piece_beg(s + 1); ++p) dma_piece(nn, nch, pb ^ 1, p, sOff[(p >> 1) * S_TPB + tid]);
+          }
+        } else {
         if (s >= 1 && s < 9 && have_next) raw_issue(nn, nch, (s - 1) % 2, dof0, dof1);
         if (s < 8) { dof0 = sOff[s * S_TPB + tid]; dof1 = sOff[(8 + s) * S_TPB + tid]; }
+        }
         if (KMH_S_ADB && s + 1 < NST) {
           const int ab = vr + a_offset(s + 1);
 #pragma unroll
@@ -1163,7 +1227,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
             for (int q = 0; q < TERMS; ++q) a[0][m][q] = sIn[q * S_PLANE + ab + m * HX];
         }
         // the next stage's voxel s - 2 (requested in the last step)
-        if (s >= 2 && s < 10) convert1(nch, cv_next, pb ^ 1, s - 2, rawq[(s - 2) % 2][0], rawq[(s - 2) % 2][1]);
+        if (!SPLIT && s >= 2 && s < 10) convert1(nch, cv_next, pb ^ 1, s - 2, rawq[(s - 2) % 2][0], rawq[(s - 2) % 2][1]);
         // term-major over the 8 x NT accumulators: per accumulator the order of conv3_fwd_bf_kernel (smallest terms first)
 #pragma unroll
         for (int q3 = 0; q3 < 3; ++q3)
@@ -1172,8 +1236,8 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
 #pragma unroll
             for (int t = 0; t < NT; ++t)
               acc[m][t] = mfma16<TERMS>(a[KMH_S_ADB ? (s & 1) : 0][m][q3 == 0 ? 1 : 0], bq[s % BD][t][q3 == 1 ? 1 : 0], acc[m][t]);
-        if (!(s >= 2 && s < 10) && KMH_S_RF) __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);      // plain steps: reads first too
-        if (s >= 2 && s < 10) {
+        if ((SPLIT || !(s >= 2 && s < 10)) && KMH_S_RF) __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);      // plain steps: reads first too
+        if (!SPLIT && s >= 2 && s < 10) {
           // every LDS read of the block first (the next step's A fragments, the coefficients, the next offsets), then a few bare
           // MFMAs while they land -- a wait in the middle of the MFMA stream stalls it --, then the conversion's VALU a few per gap
           __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);
@@ -1195,6 +1259,9 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     // are stored 16 bytes per lane (conv3_fwd_g_kernel's epilogue, 8 rows per wave).  (Forming the products transposed --
     // weights as the A operand, so that four accumulator registers are four channels of one voxel and no LDS transposition is
     // needed -- was measured: the 32-byte pieces those stores write cost 60-68k cycles per brick against 33k here.)
+    // (SPLIT: the next stage's first fragments, requested in the last BA steps, land here -- L2 hits, long issued -- so that
+    // step 0 of the next brick need not drain the queue the output stores below are about to fill)
+    if (SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int x0 = cur.bx * TX, y0 = cur.by * GTY, z0 = cur.bz * GTZ;
     constexpr int CH = 32 * NT;
     constexpr int L4 = CH / 4;
@@ -1280,7 +1347,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     stamp();                                               // epilogue issued
     if (!more) break;
     cur = nxt;
-    cv_in = inside_bits(cur);
+    if (!SPLIT) cv_in = inside_bits(cur);
     pb ^= 1;
   }
 }
@@ -2043,12 +2110,12 @@ static int launch_fwd_g(const float* x, const float* scale, const float* shift, 
   return KMH_LAUNCH_CHECK();
 }
 
-template <int NT, bool ZP = false>
+template <int NT, bool ZP = false, bool SPLIT = false>
 static int launch_fwd_s(const float* x, const float* scale, const float* shift, const bf16x8* wp, const float* bias, float* y,
                         int N, int D, int H, int W, int Cin, int Cout, int CoutP, int relu_in, int relu_out,
                         const float* ascale, const float* wscale, double* stats_ws, double* stats_out, hipStream_t s,
                         int in_blocked, const float* addend) {
-  hipError_t e = hipFuncSetAttribute((const void*)conv3_fwd_s_kernel<NT, ZP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute((const void*)conv3_fwd_s_kernel<NT, ZP, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      S_LDS_BYTES);
   if (e != hipSuccess) return (int)e;
   const int tx = ceil_div(W, TX), ty = ceil_div(H, GTY), tz = ceil_div(D, GTZ);
@@ -2061,7 +2128,7 @@ static int launch_fwd_s(const float* x, const float* scale, const float* shift, 
   static const bool tracing = getenv("KMH_G_TRACE") != nullptr;
   if (tracing && !trace) { if (hipMalloc(&trace, 240 * sizeof(long long)) != hipSuccess) trace = nullptr; }
   if (tracing && trace) (void)hipMemsetAsync(trace, 0, 240 * sizeof(long long), s);
-  conv3_fwd_s_kernel<NT, ZP><<<dim3(wgs), S_TPB, S_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in,
+  conv3_fwd_s_kernel<NT, ZP, SPLIT><<<dim3(wgs), S_TPB, S_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in,
                                                                relu_out, tx, ty, tz, tzp, ascale, wscale,
                                                                stats_out ? stats_ws : nullptr, in_blocked, addend, total, N,
                                                                tracing ? trace : nullptr);
@@ -2069,7 +2136,7 @@ static int launch_fwd_s(const float* x, const float* scale, const float* shift, 
     long long h[240];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "KMH_G_TRACE fwd_s NT=%d ZP=%d Cin=%d Cout=%d D=%d:", NT, (int)ZP, Cin, Cout, D);
+    fprintf(stderr, "KMH_G_TRACE fwd_s NT=%d ZP=%d SPLIT=%d Cin=%d Cout=%d D=%d:", NT, (int)ZP, (int)SPLIT, Cin, Cout, D);
     for (int i = 1; i < 240 && h[i]; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
     fprintf(stderr, "\n");
   }
@@ -2121,6 +2188,17 @@ KMH_API int kmh_conv3d_fwd_bf_variant(int N, int D, int H, int W, int Cin, int C
                                       int has_addend) {
   if (!fwd_g_ok(has_mask != 0, has_addend != 0, N, D, H, W, Cin, Cout, terms)) return 0;
   return use_zpair(Cout) ? 3 : (Cout > 32 ? 2 : 1);
+}
+
+/* in_blocked == 2 of kmh_conv3d_fwd_bf: x is the PRE-SPLIT channel-blocked tensor a producer such as kmh_maxpool3d_bwd_split
+ * writes -- (N, Cin/8, D*H*W + 1) records of 32 bytes = the 8 fp16 "hi" then the 8 fp16 "lo" terms of fmaf(value, S, 0) with
+ * S = ascale[0], record D*H*W of every (sample, chunk) plane all zeros -- so that the kernel copies fragments instead of
+ * converting them (conv3_fwd_s_kernel<1, true, true>).  Served: the z-paired tile (Cout <= 16) of the one-wave kernel under its
+ * usual preconditions, no scale / shift / mask / relu_in / addend (a gradient operand).  1 = served. */
+KMH_API int kmh_conv3d_fwd_bf_split_ok(int N, int D, int H, int W, int Cin, int Cout, int terms) {
+  if (!use_zpair(Cout) || Cin > S_COEF) return 0;
+  if (((long long)D * H * W + 1) * KC >= (1ll << 31)) return 0;
+  return fwd_g_ok(false, false, N, D, H, W, Cin, Cout, terms) ? 1 : 0;
 }
 
 /* Convolution + ReLU + MaxPool3d(2) in one launch, for an encoder block whose output feeds ONLY the next level's pooling
@@ -2178,6 +2256,12 @@ KMH_API int kmh_conv3d_fwd_bf(const float* x, const float* scale, const float* s
   if (terms != 2 && terms != 3) return -22;
   if (addend && use_zpair(Cout)) return -22;
   if (in_blocked && ((Cin & 7) || mask)) return -22;
+  if (in_blocked == 2) {      // pre-split input: see kmh_conv3d_fwd_bf_split_ok
+    if (!kmh_conv3d_fwd_bf_split_ok(N, D, H, W, Cin, Cout, terms) || scale || shift || relu_in || addend || !ascale || !wscale)
+      return -22;
+    return launch_fwd_s<1, true, true>(x, nullptr, nullptr, wp, bias, y, N, D, H, W, Cin, Cout, CoutP, 0, relu_out, ascale, wscale,
+                                       (double*)stats_ws, stats_out, s, 2, nullptr);
+  }
   if (terms == 2 && (!ascale || !wscale)) return -22;       // fp16 split without range scaling is not accurate
   // deep (32 x 8 x 4) bricks for the z-paired (Cout <= 16) launches on big volumes: less halo traffic, twice the B
   // reuse: +5 % on the 256^3 32->16 data gradient.  (The NT = 1, 4-rows-per-wave variant spills with 128 accumulator
@@ -2664,7 +2748,11 @@ __device__ __forceinline__ void ws_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int NT, int TERMS, bool MASK, int PW>
+// DSPLIT (round 5): dz is the pre-split record tensor of kmh_maxpool3d_bwd_split -- (N, Cout/8, V + 1) records of 8 fp16 hi +
+// 8 fp16 lo terms of fmaf(dz, S, 0) -- so a producer item (4 channels of two x neighbours) is four 8-byte loads and eight
+// 16-bit packs instead of two 16-byte loads, eight multiplies and four split_pair sequences: the same words in the same
+// transposed image, bit-identical sums.
+template <int NT, int TERMS, bool MASK, int PW, bool DSPLIT = false>
 __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_wgrad_ws_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ dz, const float* __restrict__ dzmask, float* __restrict__ partial, int N, int D,
@@ -2739,8 +2827,11 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
       di_q4[i] = on ? 4 * q : 0;                          // off: loads a valid dummy, writes zeros
       // channel-blocked dz: element offset of the quad inside the sample = (chunk plane) + voxel * 8 + (quad in chunk)
       if (dz_blocked) di_q4[i] = on ? ((co0 + 4 * q) >> 3) * (D * H * W * 8) + ((4 * q) & 7) : 0;
+      // pre-split records: planes of V + 1 records of 8 floats; the quad's four fp16 hi terms are floats (quad in chunk) / 2 ..
+      // + 1 of the record, its lo terms 4 floats further
+      if (DSPLIT) di_q4[i] = on ? ((co0 + 4 * q) >> 3) * ((D * H * W + 1) * 8) + (((4 * q) & 7) >> 1) : 0;
     }
-    const int dstride = dz_blocked ? 8 : Cout;            // floats between x neighbours of one dz quad
+    const int dstride = (dz_blocked || DSPLIT) ? 8 : Cout;      // floats between x neighbours of one dz quad
     const float sX = xscale ? xscale[0] : 1.f, sD = dscale ? dscale[0] : 1.f;
     float4 px[XI][2], pd[DI][2], pm[MASK ? DI : 1][2];
 
@@ -2749,7 +2840,8 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
     // Element offsets inside one sample are 24-bit multiply-adds (the launcher checks D*H*W*C < 2^31).
     auto issue = [&](int n, int x0, int y0, int z0) {
       const float* xn = x + (long long)n * D * H * W * Cin + ci0;
-      const float* dn = dz + (long long)n * D * H * W * Cout + (dz_blocked ? 0 : co0);
+      const float* dn = DSPLIT ? dz + (long long)n * (Cout >> 3) * ((long long)D * H * W + 1) * 8
+                               : dz + (long long)n * D * H * W * Cout + (dz_blocked ? 0 : co0);
       const float* mn = MASK ? dzmask + (long long)n * D * H * W * Cout + co0 : nullptr;
       // all element offsets first, then the loads back to back
       unsigned xo[XI][2], dO[DI][2];
@@ -2776,6 +2868,13 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
       }
 #pragma unroll
       for (int i = 0; i < DI; ++i) {
+        if constexpr (DSPLIT) {        // (hi.x, hi.y, lo.x, lo.y): 4 + 4 fp16 terms of the voxel's channel quad
+          const float2 h0 = *reinterpret_cast<const float2*>(dn + dO[i][0]), l0 = *reinterpret_cast<const float2*>(dn + dO[i][0] + 4);
+          const float2 h1 = *reinterpret_cast<const float2*>(dn + dO[i][1]), l1 = *reinterpret_cast<const float2*>(dn + dO[i][1] + 4);
+          pd[i][0] = make_float4(h0.x, h0.y, l0.x, l0.y);
+          pd[i][1] = make_float4(h1.x, h1.y, l1.x, l1.y);
+          continue;
+        }
         pd[i][0] = *reinterpret_cast<const float4*>(dn + dO[i][0]);
         pd[i][1] = *reinterpret_cast<const float4*>(dn + dO[i][1]);
         if (MASK) {
@@ -2836,6 +2935,24 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
       for (int i = 0; i < DI; ++i) {
         const int gz = z0 + (di_pk[i] & 15), gy = y0 + ((di_pk[i] >> 4) & 15), gx0 = x0 + ((di_pk[i] >> 8) & 255);
         const bool rok = (di_pk[i] >> 30) && gy < H && gz < D;
+        if constexpr (DSPLIT) {
+          // words of the transposed image: (voxel 0 | voxel 1 << 16) per channel and term
+          static_assert(TERMS == 2 && !MASK, "pre-split records are fp16 hi / lo, already masked");
+          const bool k0 = rok && gx0 < W, k1 = rok && gx0 + 1 < W;
+          unsigned a[4] = {__float_as_uint(pd[i][0].x), __float_as_uint(pd[i][0].y), __float_as_uint(pd[i][0].z), __float_as_uint(pd[i][0].w)};
+          unsigned b[4] = {__float_as_uint(pd[i][1].x), __float_as_uint(pd[i][1].y), __float_as_uint(pd[i][1].z), __float_as_uint(pd[i][1].w)};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { a[u] = k0 ? a[u] : 0u; b[u] = k1 ? b[u] : 0u; }
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned av = a[2 * t + (j >> 1)], bv = b[2 * t + (j >> 1)];
+              const unsigned wd = (j & 1) ? ((av >> 16) | (bv & 0xffff0000u)) : ((av & 0xffffu) | (bv << 16));
+              *reinterpret_cast<unsigned*>(sDT + t * CO * DPLANE + di_lds[i] + j * DPLANE) = wd;
+            }
+          continue;
+        }
         float v[2][4] = {{pd[i][0].x, pd[i][0].y, pd[i][0].z, pd[i][0].w}, {pd[i][1].x, pd[i][1].y, pd[i][1].z, pd[i][1].w}};
         float m[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
         if (MASK) {
@@ -3025,16 +3142,16 @@ static int launch_wgrad_bf(const WgradBfPlan& p, const float* x, const float* sc
   return KMH_LAUNCH_CHECK();
 }
 
-template <int NT, int TERMS, bool MASK, int PW>
+template <int NT, int TERMS, bool MASK, int PW, bool DSPLIT = false>
 static int launch_wgrad_ws(const WgradBfPlan& p, const float* x, const float* scale, const float* shift,
                            const float* dz, const float* dzmask, float* ws, int N, int D, int H, int W, int Cin,
                            int Cout, int relu_in, const float* xscale, const float* dscale, int dz_blocked, hipStream_t s) {
   const size_t lds = 2 * p.lds + 256;                      // two stages + the coefficient table
-  hipError_t e = hipFuncSetAttribute((const void*)conv3_wgrad_ws_kernel<NT, TERMS, MASK, PW>,
+  hipError_t e = hipFuncSetAttribute((const void*)conv3_wgrad_ws_kernel<NT, TERMS, MASK, PW, DSPLIT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 g(p.ci_tiles * p.co_groups * p.nslab);
-  conv3_wgrad_ws_kernel<NT, TERMS, MASK, PW><<<g, 64 * (WS_CONS + PW), lds, s>>>(x, scale, shift, dz, dzmask, ws, N, D, H, W, Cin, Cout,
+  conv3_wgrad_ws_kernel<NT, TERMS, MASK, PW, DSPLIT><<<g, 64 * (WS_CONS + PW), lds, s>>>(x, scale, shift, dz, dzmask, ws, N, D, H, W, Cin, Cout,
                                                                relu_in, p.CP, p.MT, p.TG, p.KS, p.ci_tiles, p.tiles_x,
                                                                p.tiles_y, p.tiles_z, p.bricks_per_slab, p.nslab, xscale,
                                                                dscale, dz_blocked);
@@ -3074,6 +3191,7 @@ KMH_API int kmh_conv3d_wgrad_bf(const float* x, const float* scale, const float*
   if ((w_fold == nullptr) != (bhat == nullptr)) return -22;
   const WgradBfPlan p = wgrad_bf_plan(N, D, H, W, Cin, Cout, terms);
   if (dz_blocked && (dzmask || !kmh_conv3d_wgrad_bf_blocked_ok(N, D, H, W, Cin, Cout, terms))) return -22;
+  if (dz_blocked == 2 && (terms != 2 || ((long long)D * H * W + 1) * (Cout > Cin ? Cout : Cin) >= (1ll << 31))) return -22;
   if (p.MT > p.TG * MTWB || (terms != 2 && terms != 3)) return -22;
   const int Cmem = append_ones ? Cin - 1 : Cin, ones_ch = append_ones ? Cin - 1 : -1;
   if (append_ones && (scale || Cin > 4)) return -22;
@@ -3084,7 +3202,10 @@ KMH_API int kmh_conv3d_wgrad_bf(const float* x, const float* scale, const float*
   const bool ws_ok = wgrad_ws_ok(p, D, H, W, Cin, Cout, terms) && !append_ones;
 #define KMH_WS_CALL(NT_, M_, PW_) launch_wgrad_ws<NT_, 2, M_, PW_>(p, x, scale, shift, dz, dzmask, (float*)ws, N, D, H, W, Cin, Cout, relu_in, xscale, dscale, dz_blocked, s)
   static const int pw = getenv("KEYMORPH_WGRAD_PRODUCERS") ? atoi(getenv("KEYMORPH_WGRAD_PRODUCERS")) : 8;
-  if (ws_ok) {
+  if (ws_ok && dz_blocked == 2) {      // pre-split dz records (kmh_maxpool3d_bwd_split)
+    rc = p.NT == 2 ? launch_wgrad_ws<2, 2, false, 8, true>(p, x, scale, shift, dz, nullptr, (float*)ws, N, D, H, W, Cin, Cout, relu_in, xscale, dscale, 0, s)
+                   : launch_wgrad_ws<1, 2, false, 8, true>(p, x, scale, shift, dz, nullptr, (float*)ws, N, D, H, W, Cin, Cout, relu_in, xscale, dscale, 0, s);
+  } else if (ws_ok) {
     if (p.NT == 2) rc = dzmask ? KMH_WS_CALL(2, true, 4) : (pw == 8 ? KMH_WS_CALL(2, false, 8) : KMH_WS_CALL(2, false, 4));
     else rc = dzmask ? KMH_WS_CALL(1, true, 4) : (pw == 8 ? KMH_WS_CALL(1, false, 8) : KMH_WS_CALL(1, false, 4));
   } else if (p.NT == 2) rc = terms == 2 ? KMH_WG_CALL(2, 2) : KMH_WG_CALL(2, 3);

@@ -621,6 +621,55 @@ __global__ __launch_bounds__(TPB) void maxpool_bwd4_rows_kernel(const unsigned* 
   }
 }
 
+// The same scatter written ALREADY SPLIT for the 16-bit matrix cores (round 5): the consumer -- the data-gradient convolution of
+// the block in front of the pooling, conv3_fwd_s_kernel<1, true, true> -- then copies fragments instead of converting them.
+// A scatter moves values, so the range scale S of the pooled gradient (known before this pass, carried with the tensor) is the
+// scale of its output: every 32-byte record (one voxel, one 8-channel chunk) holds the 8 fp16 "hi" then the 8 fp16 "lo" terms of
+// fmaf(value, S, 0) -- exactly what the consumer's own conversion computes from the fp32 tensor, so results are bit-identical --
+// and record V of every (sample, chunk) plane is zero (the source of the consumer's padding slots).  Same bytes, same store
+// pattern as the kernel above (lane = one 16-byte piece in memory order; the two lanes of a record compute both halves and
+// store one each).
+__global__ __launch_bounds__(TPB) void maxpool_bwd4_split_kernel(const unsigned* __restrict__ argm, const float4* __restrict__ dy,
+                                                                 const float* __restrict__ scale2, float* __restrict__ dx, int D,
+                                                                 int H, int W, int C4, int Do, int Ho, int Wo) {
+  const int n = blockIdx.y;
+  const long long V = (long long)D * H * W;
+  const long long pooled = (long long)Do * Ho * Wo * C4;
+  const int nchunk = C4 >> 1;
+  float* dxn = dx + (long long)n * nchunk * (V + 1) * 8;
+  const float S = scale2[0];
+  if (blockIdx.x == 0) {                                    // the zero records
+    for (int e = threadIdx.x; e < nchunk * 2; e += TPB)
+      *reinterpret_cast<float4*>(dxn + ((long long)(e >> 1) * (V + 1) + V) * 8 + 4 * (e & 1)) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int ppr = Wo * 4;                                   // pieces per pooled row
+  const long long total = (long long)nchunk * Do * Ho * ppr;
+  for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+    const int p = (int)(e % ppr);
+    const long long r = e / ppr;
+    const int yo = (int)(r % Ho), zo = (int)((r / Ho) % Do), chunk = (int)(r / ((long long)Ho * Do));
+    const int xo = p >> 2, dxx = (p >> 1) & 1, half = p & 1;
+    const long long idx = (((long long)zo * Ho + yo) * Wo + xo) * C4 + 2 * chunk;
+    const uint2 a2 = *reinterpret_cast<const uint2*>(argm + (long long)n * pooled + idx);
+    const float4 g0 = dy[(long long)n * pooled + idx], g1 = dy[(long long)n * pooled + idx + 1];
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    int a[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = (a2.x >> (8 * j)) & 255; a[4 + j] = (a2.y >> (8 * j)) & 255; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = 2 * kk + dxx;                            // window index (dz, dy, dx)
+      const long long vox = ((long long)(2 * zo + (kk >> 1)) * H + 2 * yo + (kk & 1)) * W + 2 * xo + dxx;
+      float val[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) val[j] = fmaf(k == a[j] ? g[j] : 0.f, S, 0.f);
+      kmh_bf16x8 parts[2];
+      split8<2>(val, parts);
+      *reinterpret_cast<kmh_bf16x8*>(dxn + ((long long)chunk * (V + 1) + vox) * 8 + 4 * half) = half ? parts[1] : parts[0];
+    }
+  }
+}
+
 // Pooling backward + skip gradient, with the skip gradient's GroupNorm backward still pending (round 3): the decoder's
 // fused upsample + concat + conv operator returns its normalised-input gradient dxn for the skip half untouched, and this
 // kernel forms  dx = scatter(dy) + [x > 0] (c1 dxn + c2 x + c3)  in one pass over the encoder output x -- the separate
@@ -1162,6 +1211,27 @@ KMH_API int kmh_maxpool3d_bwd(const float* x, const unsigned char* argmax, const
     maxpool_bwd_kernel<<<dim3(stream_blocks(pooled), N), TPB, 0, (hipStream_t)stream>>>(
         x, argmax, dy, add, add_cstride, dx, D, H, W, C, Do, Ho, Wo, out_blocked);
   }
+  return KMH_LAUNCH_CHECK();
+}
+
+/* MaxPool3d(2)'s backward written PRE-SPLIT for kmh_conv3d_fwd_bf(in_blocked = 2): dxs is (N, C/8, D*H*W + 1) records of 32
+ * bytes -- 8 fp16 hi + 8 fp16 lo terms of fmaf(scatter(dy), S, 0), S = dy_scale2[0] (the {S, 1/S} range scale of dy, which a
+ * scatter keeps), record D*H*W of every plane zero; kmh_maxpool3d_bwd_split_bytes gives its size.  Even D, H, W, C % 8 == 0,
+ * winners as recorded by kmh_maxpool3d_fwd / kmh_conv3d_fwd_bf_pool.  (Autograd of max_pool3d,
+ * keymorph/unet3d/buildingblocks.py:321-380, in the operand format of the data gradient that consumes it.) */
+KMH_API size_t kmh_maxpool3d_bwd_split_bytes(int N, int D, int H, int W, int C) {
+  return (size_t)N * (C / 8) * ((size_t)D * H * W + 1) * 32;
+}
+KMH_API int kmh_maxpool3d_bwd_split(const unsigned char* argmax, const float* dy, const float* dy_scale2, float* dxs, int N,
+                                    int D, int H, int W, int C, void* stream) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const long long pooled = (long long)Do * Ho * Wo * C;
+  if (!argmax || !dy || !dy_scale2 || !dxs || (C & 7) || (D & 1) || (H & 1) || (W & 1) || N <= 0 || D <= 0 || H <= 0 || W <= 0)
+    return -22;
+  if (pooled / 4 >= (1ll << 31) || (long long)D * H * W >= (1ll << 31)) return -22;
+  if ((((uintptr_t)dxs | (uintptr_t)dy) & 15) || ((uintptr_t)argmax & 7)) return -22;
+  maxpool_bwd4_split_kernel<<<dim3(stream_blocks(pooled), N), TPB, 0, (hipStream_t)stream>>>(
+      (const unsigned*)argmax, (const float4*)dy, dy_scale2, dxs, D, H, W, C / 4, Do, Ho, Wo);
   return KMH_LAUNCH_CHECK();
 }
 

@@ -545,3 +545,153 @@ def test_training_steps_repeat_bit_for_bit(dispatch):
         assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
     finally:
         B.set_conv_mode(old)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 5: the pre-split operand path -- the pooling backward writes fp16 hi / lo records, the z-paired data gradient copies
+# them (conv3_fwd_s_kernel<1, true, true>: LDS-DMA pieces, no conversion)
+def _pool_bwd_pair(N, shape, C, seed):
+    """-> (pooled gradient (N, D/2, H/2, W/2, C), winners (same, uint8 in 0..7), its device range scale {S, 1/S})"""
+    from keymorph_amd import backbone_ops as B
+    D, H, W = shape
+    g = gen(seed)
+    dy = torch.randn(N, D // 2, H // 2, W // 2, C, generator=g).to(DEV)
+    dy[0, 0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1e-30, -3.5])          # zeros of both signs, a tiny value
+    arg = torch.randint(0, 8, (N, D // 2, H // 2, W // 2, C), generator=g, dtype=torch.uint8).to(DEV)
+    return dy.contiguous(), arg.contiguous(), B.absmax_scale(dy)
+
+
+@pytest.mark.parametrize("N,shape,C", [(2, (8, 16, 64), 32), (1, (12, 20, 34), 32), (3, (6, 10, 70), 16), (1, (4, 8, 32), 64)])
+def test_pool_backward_split_records_are_the_consumers_own_split(N, shape, C):
+    """kmh_maxpool3d_bwd_split: every record = (fp16 hi, fp16 lo) of fmaf(scatter(dy), S, 0) exactly as split8<2> forms them
+    (hi = round-to-nearest fp16, lo = fp16 of the exact residual), the plane's last record zero -- checked against the dense
+    scatter (kmh_maxpool3d_bwd) split on the host."""
+    from keymorph_amd import _lib
+    from keymorph_amd.ops import _p, _stream, check
+    lib = _lib.load()
+    D, H, W = shape
+    V = D * H * W
+    dy, arg, sc = _pool_bwd_pair(N, shape, C, 5)
+    dense = torch.empty(N, D, H, W, C, device=DEV)
+    check(lib.kmh_maxpool3d_bwd(None, _p(arg), _p(dy), None, 0, _p(dense), N, D, H, W, C, 0, _stream()), "bwd")
+    assert lib.kmh_maxpool3d_bwd_split_bytes(N, D, H, W, C) == N * (C // 8) * (V + 1) * 32
+    rec = torch.full((N, C // 8, V + 1, 16), -1, dtype=torch.int16, device=DEV)
+    check(lib.kmh_maxpool3d_bwd_split(_p(arg), _p(dy), _p(sc), _p(rec), N, D, H, W, C, _stream()), "split")
+    S = float(sc[0])
+    v = (dense.double() * S).reshape(N, V, C // 8, 8).permute(0, 2, 1, 3)            # (N, chunk, V, 8), exact in fp64
+    hi = v.to(torch.float32).to(torch.float16)
+    lo = (v - hi.double()).to(torch.float32).to(torch.float16)
+    got = rec.view(torch.float16)
+    assert torch.equal(got[:, :, :V, :8].float(), hi.float()) and torch.equal(got[:, :, :V, 8:].float(), lo.float())
+    assert int(rec[:, :, V, :].abs().max()) == 0
+
+
+@pytest.mark.parametrize("N,shape,Cin,Cout", [(2, (8, 16, 64), 32, 16), (1, (12, 20, 34), 32, 16), (3, (6, 10, 70), 16, 8),
+                                              (1, (4, 8, 32), 64, 16), (2, (44, 60, 100), 32, 16)])
+def test_presplit_data_gradient_is_bit_identical_to_the_fp32_operand(N, shape, Cin, Cout, dispatch):
+    """The z-paired data gradient on the pre-split records (in_blocked = 2) against the same launch on the channel-blocked fp32
+    scatter (in_blocked = 1: conv3_fwd_g_kernel<1,true>) and on the dense one (conv3_fwd_bf_kernel): identical bits, with the
+    output statistics the GroupNorm backward takes from the epilogue."""
+    from keymorph_amd import _lib, backbone_ops as B
+    from keymorph_amd.ops import _p, _stream, check
+    lib = _lib.load()
+    B.set_conv_mode("f16x3")
+    D, H, W = shape
+    V = D * H * W
+    dy, arg, sc = _pool_bwd_pair(N, shape, Cin, 7)
+    w = (torch.randn(Cin, Cout, 3, 3, 3, generator=gen(8)) * 0.05).to(DEV)        # (Cout_w, Cin_w) = (Cin, Cout) of this view
+    pk = B.pack_weight(w, True)
+    dense = torch.empty(N, D, H, W, Cin, device=DEV)
+    blocked = torch.empty(N, Cin // 8, D, H, W, 8, device=DEV)
+    rec = torch.empty((N, Cin // 8, V + 1, 8), device=DEV)
+    check(lib.kmh_maxpool3d_bwd(None, _p(arg), _p(dy), None, 0, _p(dense), N, D, H, W, Cin, 0, _stream()), "bwd")
+    check(lib.kmh_maxpool3d_bwd(None, _p(arg), _p(dy), None, 0, _p(blocked), N, D, H, W, Cin, 1, _stream()), "bwd blocked")
+    check(lib.kmh_maxpool3d_bwd_split(_p(arg), _p(dy), _p(sc), _p(rec), N, D, H, W, Cin, _stream()), "bwd split")
+    dispatch(2)
+    assert lib.kmh_conv3d_fwd_bf_split_ok(N, D, H, W, Cin, Cout, 2) == 1
+    st = {k: torch.empty((N, Cout, 2), dtype=torch.float64, device=DEV) for k in ("blocked", "split")}
+    y_b = B.conv3_raw(blocked, None, None, pk, None, N, D, H, W, Cin, Cout, False, False, ascale=sc, in_blocked=True,
+                      stats_out=st["blocked"])
+    y_s = B.conv3_raw(rec, None, None, pk, None, N, D, H, W, Cin, Cout, False, False, ascale=sc, in_blocked=2,
+                      stats_out=st["split"])
+    dispatch(0)
+    y_d = B.conv3_raw(dense, None, None, pk, None, N, D, H, W, Cin, Cout, False, False, ascale=sc)
+    assert torch.isfinite(y_s).all() and float(y_s.abs().max()) > 0
+    assert torch.equal(y_s, y_b), float((y_s - y_b).abs().max())
+    assert torch.equal(y_s, y_d)
+    ref = conv3_fp64(dense.double().cpu(), w.double().cpu().permute(1, 0, 2, 3, 4).flip(2, 3, 4).contiguous())
+    assert rel(y_s.cpu(), ref) < 3e-6
+    # statistics: the same outputs summed (grouped by wave = plane pair in the one-wave kernel, by (pair, row quarter) before)
+    assert rel(st["split"].cpu(), st["blocked"].cpu().double()) < 1e-6
+    # repeated launches (the deep fragment ring and the sparse drains): same bits
+    for _ in range(3):
+        torch.empty(64 << 20, device=DEV).normal_()          # evict
+        dispatch(2)
+        again = B.conv3_raw(rec, None, None, pk, None, N, D, H, W, Cin, Cout, False, False, ascale=sc, in_blocked=2)
+        assert torch.equal(again, y_s)
+
+
+def test_presplit_operand_refused_where_it_is_not_served(dispatch):
+    from keymorph_amd import _lib
+    lib = _lib.load()
+    dispatch(2)
+    assert lib.kmh_conv3d_fwd_bf_split_ok(1, 8, 16, 64, 32, 32, 2) == 0           # not the z-paired tile
+    assert lib.kmh_conv3d_fwd_bf_split_ok(1, 8, 16, 64, 32, 16, 3) == 0           # bf16x6
+    assert lib.kmh_conv3d_fwd_bf_split_ok(1, 8, 16, 64, 12, 16, 2) == 0           # whole chunks only
+    dispatch(1)
+    assert lib.kmh_conv3d_fwd_bf_split_ok(1, 8, 16, 64, 32, 16, 2) == 0           # below 512 bricks in the default mode
+    assert lib.kmh_conv3d_fwd_bf_split_ok(4, 256, 256, 256, 32, 16, 2) == 1
+
+
+@pytest.mark.parametrize("cfg", [(2, (12, 16, 64), 16, 32), (2, (44, 60, 100), 16, 32), (1, (30, 62, 122), 8, 24)])
+def test_conv_pool_backward_with_presplit_scatter_equals_the_fp32_scatter(cfg, dispatch, monkeypatch):
+    """The conv + pooling operator's backward with its pooled gradient scattered straight into pre-split records (both the
+    z-paired data gradient and the wave-specialised weight gradient read them) against the same backward on the channel-
+    blocked fp32 scatter (KEYMORPH_NO_SPLIT_POOLGRAD=1): every gradient -- weights, GroupNorm affine, input -- bit for bit,
+    and the weight gradient against fp64 autograd of keymorph/unet3d/buildingblocks.py:46-78 + max_pool3d."""
+    from keymorph_amd import backbone_ops as B
+    N, dims, Cin, Cout = cfg
+    D, H, W = dims
+    old = B.CONV_MODE
+    try:
+        B.set_conv_mode("f16x3")
+        dispatch(2)
+        assert B.conv_pool_ok(N, D, H, W, Cin, Cout) and B.grad_blocked_ok(N, D, H, W, Cin, Cout)
+        g = gen(600 + Cin)
+        x = (torch.randn(N, D, H, W, Cin, generator=g).abs() + 0.1 * torch.randn(N, D, H, W, Cin, generator=g)).to(DEV)
+        gamma, beta = (1 + 0.2 * torch.randn(Cin, generator=g)).to(DEV), (0.2 * torch.randn(Cin, generator=g)).to(DEV)
+        w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / np.sqrt(27 * Cin)).to(DEV)
+        cot = torch.randn(N, D // 2, H // 2, W // 2, Cout, generator=g).to(DEV)
+        G = 8
+
+        def run(split):
+            if split:
+                monkeypatch.delenv("KEYMORPH_NO_SPLIT_POOLGRAD", raising=False)
+            else:
+                monkeypatch.setenv("KEYMORPH_NO_SPLIT_POOLGRAD", "1")
+            Hh = [t.clone().requires_grad_(True) for t in (x, gamma, beta, w)]
+            before = B.SPLIT_STATS["handoffs"]
+            yp = B.single_conv_gcr(*Hh, G, x_from_relu=False, dy_premasked=True, dy_blocked=True, pool=True)
+            (yp * (cot * (yp.detach() > 0))).sum().backward()
+            assert B.SPLIT_STATS["handoffs"] == before + int(split)
+            return yp.detach(), [t.grad for t in Hh]
+
+        assert B.pool_grad_split_ok(N, D, H, W, Cin, Cout)
+        ys, gs = run(True)
+        yb, gb = run(False)
+        assert torch.equal(ys, yb)
+        # the weight gradient is the same sum of the same words: identical bits.  The normalised-input gradient dxn is too
+        # (test_presplit_data_gradient_is_bit_identical_to_the_fp32_operand), but GroupNorm's backward takes sum(dxn) from the
+        # convolution's epilogue, and the one-wave kernel groups those partial sums by wave = plane pair where the eight-wave
+        # kernel of the fp32 route groups them by (pair, row quarter): the coefficients, and with them dx / dgamma / dbeta,
+        # agree to fp32 rounding of the partial sums
+        assert torch.isfinite(gs[3]).all() and torch.equal(gs[3], gb[3]), float((gs[3] - gb[3]).abs().max())
+        for name, a, b in zip(("x", "gamma", "beta"), gs, gb):
+            assert torch.isfinite(a).all() and rel(a, b.double()) < 2e-6, (name, rel(a, b.double()))
+        R = [t.double().cpu().requires_grad_(True) for t in (x, gamma, beta, w)]
+        y64 = torch.relu(conv3_fp64(group_norm_fp64(R[0], G, R[1], R[2]), R[3]))
+        p64 = F.max_pool3d(y64.permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1)
+        (p64 * (cot.cpu().double() * (p64.detach() > 0))).sum().backward()
+        assert rel(gs[3].cpu(), R[3].grad) < 5e-6 and rel(gs[0].cpu(), R[0].grad) < 2e-5
+    finally:
+        B.set_conv_mode(old)
