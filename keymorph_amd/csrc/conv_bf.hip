@@ -928,15 +928,23 @@ static_assert(GPL <= S_PLANE && GTZ == 4 && GTY == S_MR, "wave = plane, 8 rows")
 // conversion cannot hide: the z-paired 32 -> 16 data gradient at 256^3 has 18 x 12 MFMAs per chunk (6.9k cycles) against a
 // conversion of the same length (cycle stamps, profiles/r5a): 1300-1800 cycles per conversion step against 384 of MFMA time.
 // Bit-identical to the fp32 input: the producer applies the same fmaf(x, S, 0) and split8<2>.
-template <int NT, bool ZP = false, bool SPLIT = false>
+// POOL (round 5; NT = 1, not z-paired: 16 < Cout <= 32): the pooling epilogue of conv3_fwd_g_kernel on this kernel's waves -- a
+// wave holds one PLANE of the brick (8 rows), so the x children of a window meet in one lane of the row tile's read-back, its
+// y children in consecutive rows of the same wave, and its z children in the wave next to it (odd planes publish their
+// (x, y)-pooled partials through LDS); ATen's first-max rule, the same winners, the same outputs bit for bit.  What it buys:
+// the plain one-wave kernel spends 38 % of a two-chunk 16 -> 32 brick in its epilogue storing 128 KB (cycle stamps, r5a); the
+// pooled tensor is 16 KB.
+template <int NT, bool ZP = false, bool SPLIT = false, bool POOL = false>
 __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16x8* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int D, int H, int W, int Cin,
     int Cout, int CoutP, int relu_in, int relu_out, int tiles_x, int tiles_y, int tiles_z, int tiles_zp,
     const float* __restrict__ ascale, const float* __restrict__ wscale, double* __restrict__ stats_partial,
-    int in_blocked, const float* __restrict__ addend, int total_items, int N, long long* __restrict__ trace) {
+    int in_blocked, const float* __restrict__ addend, int total_items, int N, long long* __restrict__ trace,
+    unsigned* __restrict__ pool_arg = nullptr) {
   constexpr int TERMS = 2, MR = ZP ? 4 : S_MR, NST = ZP ? NSTEP_Z : NSTEP;
   static_assert(!ZP || NT == 1, "z-paired tiles are for Cout <= 16");
+  static_assert(!POOL || (NT == 1 && !ZP), "the pooling epilogue is built for the 32-wide tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   int* sOff = reinterpret_cast<int*>(gsm + 2 * S_BUF_BYTES);
   float* sCoef = reinterpret_cast<float*>(gsm + 2 * S_BUF_BYTES + S_OFF_BYTES);
@@ -1280,6 +1288,96 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                           // every wave is done with the fragment images
     const int gz = z0 + wz + pl;
+    if constexpr (POOL) {
+      // lane = (channel quad c4, x-pair group j): row m's tile is read back as voxel PAIRS (2 j + 16 kk, + 1); rows 2 p, 2 p + 1
+      // are the y children of window row p; planes wz (even) and wz + 1 the z children.  Scan order of the reference (z, y, x;
+      // a later value wins only if strictly greater, or NaN): lower-index halves are combined first.
+      const int j = lane >> 3;
+      float4 pm[MR / 2][2];
+      unsigned pa[MR / 2][2];
+      auto pick = [](float a, float b, unsigned ca, unsigned cb, float& m_, unsigned& c_) {
+        const bool tb = (b > a) || (b != b);
+        m_ = tb ? b : a; c_ = tb ? cb : ca;
+      };
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        float* tile = tile0 + (m & 1) * (32 * CH);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * CH + li] = acc[m][0][r];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int xe = 2 * j + 16 * kk;
+          const float4 a = *reinterpret_cast<const float4*>(tile + xe * CH + col);
+          const float4 b = *reinterpret_cast<const float4*>(tile + (xe + 1) * CH + col);
+          float va[4] = {a.x * desc + bv.x, a.y * desc + bv.y, a.z * desc + bv.z, a.w * desc + bv.w};
+          float vb[4] = {b.x * desc + bv.x, b.y * desc + bv.y, b.z * desc + bv.z, b.w * desc + bv.w};
+          float mx[4];
+          unsigned cx[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (relu_out) { va[q] = fmaxf(va[q], 0.f); vb[q] = fmaxf(vb[q], 0.f); }
+            pick(va[q], vb[q], 0u, 1u, mx[q], cx[q]);                      // x children: codes 0 / 1
+          }
+          if ((m & 1) == 0) {
+            pm[m >> 1][kk] = float4{mx[0], mx[1], mx[2], mx[3]};
+            pa[m >> 1][kk] = cx[0] | (cx[1] << 8) | (cx[2] << 16) | (cx[3] << 24);
+          } else {                                                         // y children: + 2 for the second row
+            float4& P = pm[m >> 1][kk];
+            const unsigned A = pa[m >> 1][kk];
+            float o0, o1, o2, o3;
+            unsigned c0, c1, c2, c3;
+            pick(P.x, mx[0], A & 255u, cx[0] + 2u, o0, c0);
+            pick(P.y, mx[1], (A >> 8) & 255u, cx[1] + 2u, o1, c1);
+            pick(P.z, mx[2], (A >> 16) & 255u, cx[2] + 2u, o2, c2);
+            pick(P.w, mx[3], A >> 24, cx[3] + 2u, o3, c3);
+            P = float4{o0, o1, o2, o3};
+            pa[m >> 1][kk] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+          }
+        }
+      }
+      // z children: waves 1, 3 (odd planes) publish, waves 0, 2 combine and store
+      constexpr int XN = (MR / 2) * 2 * 64;                                // records per plane pair
+      float4* xv = reinterpret_cast<float4*>(sEp + 4 * (2 * 32 * CH) * 4);   // behind the 4 x 2 row tiles (32 KB)
+      unsigned* xa = reinterpret_cast<unsigned*>(xv + 2 * XN);
+      const bool odd_plane = (wv & 1) != 0;
+      const int slot = (wv >> 1) * XN;
+      if (odd_plane) {
+#pragma unroll
+        for (int p = 0; p < MR / 2; ++p)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) { xv[slot + (2 * p + kk) * 64 + lane] = pm[p][kk]; xa[slot + (2 * p + kk) * 64 + lane] = pa[p][kk]; }
+      }
+      __syncthreads();
+      if (!odd_plane) {
+        const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1;
+        const int oz = (z0 + wz) >> 1;
+#pragma unroll
+        for (int p = 0; p < MR / 2; ++p) {
+          const int oy = (y0 + 2 * p) >> 1;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int ox = (x0 >> 1) + j + 8 * kk;
+            const float4 Q = xv[slot + (2 * p + kk) * 64 + lane];
+            const unsigned B = xa[slot + (2 * p + kk) * 64 + lane];
+            const float4 P = pm[p][kk];
+            const unsigned A = pa[p][kk];
+            float o0, o1, o2, o3;
+            unsigned c0, c1, c2, c3;
+            pick(P.x, Q.x, A & 255u, (B & 255u) + 4u, o0, c0);
+            pick(P.y, Q.y, (A >> 8) & 255u, ((B >> 8) & 255u) + 4u, o1, c1);
+            pick(P.z, Q.z, (A >> 16) & 255u, ((B >> 16) & 255u) + 4u, o2, c2);
+            pick(P.w, Q.w, A >> 24, (B >> 24) + 4u, o3, c3);
+            if (oz < Do && oy < Ho && ox < Wo && co_ok) {
+              const long long e = ((((long long)n * Do + oz) * Ho + oy) * Wo + ox) * Cout + co;
+              *reinterpret_cast<float4*>(y + e) = float4{o0, o1, o2, o3};
+              pool_arg[e >> 2] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+              st1[0] += o0; st2[0] += o0 * o0; st1[1] += o1; st2[1] += o1 * o1;
+              st1[2] += o2; st2[2] += o2 * o2; st1[3] += o3; st2[3] += o3 * o3;
+            }
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
       float* tile = tile0 + (m & 1) * (32 * CH);
@@ -1312,6 +1410,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
         }
       }
     }
+    }   // !POOL
     if (stats_partial) {
       double d1[4], d2[4];
 #pragma unroll
@@ -2110,12 +2209,12 @@ static int launch_fwd_g(const float* x, const float* scale, const float* shift, 
   return KMH_LAUNCH_CHECK();
 }
 
-template <int NT, bool ZP = false, bool SPLIT = false>
+template <int NT, bool ZP = false, bool SPLIT = false, bool POOL = false>
 static int launch_fwd_s(const float* x, const float* scale, const float* shift, const bf16x8* wp, const float* bias, float* y,
                         int N, int D, int H, int W, int Cin, int Cout, int CoutP, int relu_in, int relu_out,
                         const float* ascale, const float* wscale, double* stats_ws, double* stats_out, hipStream_t s,
-                        int in_blocked, const float* addend) {
-  hipError_t e = hipFuncSetAttribute((const void*)conv3_fwd_s_kernel<NT, ZP, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        int in_blocked, const float* addend, unsigned* pool_arg = nullptr) {
+  hipError_t e = hipFuncSetAttribute((const void*)conv3_fwd_s_kernel<NT, ZP, SPLIT, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      S_LDS_BYTES);
   if (e != hipSuccess) return (int)e;
   const int tx = ceil_div(W, TX), ty = ceil_div(H, GTY), tz = ceil_div(D, GTZ);
@@ -2128,15 +2227,15 @@ static int launch_fwd_s(const float* x, const float* scale, const float* shift, 
   static const bool tracing = getenv("KMH_G_TRACE") != nullptr;
   if (tracing && !trace) { if (hipMalloc(&trace, 240 * sizeof(long long)) != hipSuccess) trace = nullptr; }
   if (tracing && trace) (void)hipMemsetAsync(trace, 0, 240 * sizeof(long long), s);
-  conv3_fwd_s_kernel<NT, ZP, SPLIT><<<dim3(wgs), S_TPB, S_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in,
+  conv3_fwd_s_kernel<NT, ZP, SPLIT, POOL><<<dim3(wgs), S_TPB, S_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in,
                                                                relu_out, tx, ty, tz, tzp, ascale, wscale,
                                                                stats_out ? stats_ws : nullptr, in_blocked, addend, total, N,
-                                                               tracing ? trace : nullptr);
+                                                               tracing ? trace : nullptr, pool_arg);
   if (tracing && trace) {
     long long h[240];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "KMH_G_TRACE fwd_s NT=%d ZP=%d SPLIT=%d Cin=%d Cout=%d D=%d:", NT, (int)ZP, (int)SPLIT, Cin, Cout, D);
+    fprintf(stderr, "KMH_G_TRACE fwd_s NT=%d ZP=%d SPLIT=%d POOL=%d Cin=%d Cout=%d D=%d:", NT, (int)ZP, (int)SPLIT, (int)POOL, Cin, Cout, D);
     for (int i = 1; i < 240 && h[i]; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
     fprintf(stderr, "\n");
   }
@@ -2218,6 +2317,13 @@ KMH_API int kmh_conv3d_fwd_bf_pool(const float* x, const float* scale, const flo
                                    int in_blocked, void* stream) {
   if (!kmh_conv3d_fwd_bf_pool_ok(N, D, H, W, Cin, Cout, terms) || !ascale || !wscale || !yp || !arg) return -22;
   if (((uintptr_t)yp & 15) || ((uintptr_t)arg & 3)) return -22;
+  // the one-wave kernel's pooling epilogue (KEYMORPH_FWD_S=0 or KEYMORPH_POOL_G=1: the eight-wave kernel's, the A/B arm;
+  // same pooled values and winners)
+  static const bool pool_g = (getenv("KEYMORPH_FWD_S") && atoi(getenv("KEYMORPH_FWD_S")) == 0) || getenv("KEYMORPH_POOL_G") != nullptr;
+  if (!pool_g && Cin <= S_COEF)
+    return launch_fwd_s<1, false, false, true>(x, scale, shift, (const bf16x8*)packed, nullptr, yp, N, D, H, W, Cin, Cout,
+                                               cout_pad(Cout), relu_in, 1, ascale, wscale, (double*)stats_ws, stats_out,
+                                               (hipStream_t)stream, in_blocked, nullptr, (unsigned*)arg);
   return launch_fwd_g<1, false, true>(x, scale, shift, (const bf16x8*)packed, nullptr, yp, N, D, H, W, Cin, Cout,
                                       cout_pad(Cout), relu_in, 1, ascale, wscale, (double*)stats_ws, stats_out,
                                       (hipStream_t)stream, in_blocked, nullptr, (unsigned*)arg);
