@@ -287,6 +287,63 @@ def cpu_baseline_at_size(size, keypoints, threads):
             "keypoints": keypoints, "mem_available_gib": avail, "ref": ref}
 
 
+def gpu_sensors(device_index):
+    """(power in W, shader clock in MHz) of this rank's GPU from the amdgpu hwmon files -- power1_average (uW) and freq1_input
+    (Hz) under /sys/class/drm/card*/device/hwmon/hwmon*/ -- matched to the HIP device by PCI bus id; (None, None) when the
+    files are not there.  No rocm-smi, no extra process: two small file reads right after the timed steps."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+    except Exception:      # noqa: BLE001
+        want = None
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    hit = None
+    for c in cards:
+        try:
+            if want and os.path.basename(os.path.realpath(c)).startswith(want):
+                hit = c
+                break
+        except OSError:
+            pass
+    if hit is None and len(cards) > device_index and want is None:
+        hit = cards[device_index]
+    if hit is None:
+        return None, None
+
+    def rd(pat):
+        for f in glob.glob(os.path.join(hit, "hwmon", "hwmon*", pat)):
+            try:
+                return float(open(f).read().strip())
+            except (OSError, ValueError):
+                pass
+        return None
+    pw, fq = rd("power1_average"), rd("freq1_input")
+    if pw is None:
+        pw = rd("power1_input")
+    return (pw / 1e6 if pw is not None else None), (fq / 1e6 if fq is not None else None)
+
+
+def rccl_transport_summary(path):
+    """What the RCCL debug log of rank 0's communicator set-up says about the wires: counts of the `via <transport>` suffixes
+    of its channel lines (P2P/IPC = xGMI or PCIe peer access, SHM = host memory, NET/... = sockets / IB) plus the lines that
+    name xGMI / the chosen algorithm.  The first 8-GPU run then says by itself which transport carried the all-reduce."""
+    import collections
+    import re
+    via, notes = collections.Counter(), []
+    try:
+        for line in open(path, errors="replace"):
+            m = re.search(r" via (\S+)", line)
+            if m:
+                via[m.group(1)] += 1
+            if re.search(r"xgmi|XGMI|Connected all rings|Connected all trees|NCCL_ALGO|NCCL_PROTO|Using network|comm 0x.* rank 0 nranks", line):
+                if len(notes) < 12:
+                    notes.append(line.strip()[-160:])
+    except OSError as e:
+        return {"error": f"no RCCL debug log: {e}"}
+    return {"via": dict(via), "lines": notes}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -298,6 +355,15 @@ def main():
     if a.gpus > 1 and not launch_check and os.environ.get("KEYMORPH_SHARE_GPU") != "1" and visible_devices() < a.gpus:
         print(f"bench.py: --gpus {a.gpus} needs {a.gpus} visible devices, this box shows {visible_devices()}", file=sys.stderr)
         sys.exit(2)
+    rccl_log = None
+    if a.gpus > 1 and int(os.environ.get("RANK", "0")) == 0 and not launch_check and "NCCL_DEBUG" not in os.environ:
+        # rank 0's communicator set-up says which transport carries the gradients: keep its debug log (INIT / GRAPH only: a few
+        # dozen lines, written once when the first collective builds the communicator)
+        import tempfile
+        rccl_log = os.path.join(tempfile.gettempdir(), f"keymorph_rccl_rank0_{os.getpid()}.log")
+        os.environ["NCCL_DEBUG"] = "INFO"
+        os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,ENV"
+        os.environ["NCCL_DEBUG_FILE"] = rccl_log
     rank, local, world = parallel.init_distributed()
     if launch_check:
         # launcher test hook: the process group the gradients would use, one collective, no HIP work
@@ -339,9 +405,16 @@ def main():
         loss = train_step(model, flat, opt, img_f, img_m, tt)
     sync()
     dt = time.perf_counter() - t0
+    power_w, sclk_mhz = gpu_sensors(dev.index if dev.index is not None else 0)      # right after the timed steps
+    sensors = torch.tensor([power_w if power_w is not None else float("nan"), sclk_mhz if sclk_mhz is not None else float("nan")],
+                           dtype=torch.float64, device=dev)
+    rank_sensors = [sensors.tolist()]
     rank_ms = [1000 * dt / a.steps]
     allreduce_ms = 0.0
     if world > 1:
+        every_s = [torch.empty_like(sensors) for _ in range(world)]
+        torch.distributed.all_gather(every_s, sensors)
+        rank_sensors = [x.tolist() for x in every_s]
         t = torch.tensor([dt], device=dev)
         every = [torch.empty_like(t) for _ in range(world)]
         torch.distributed.all_gather(every, t)
@@ -642,6 +715,15 @@ def main():
                 "launcher": ("bench.py self_launch" if os.environ.get("KEYMORPH_BENCH_SELF_LAUNCHED") == "1" else
                              "torch.distributed.run / external") if world > 1 else None,
                 "rank_ms_per_step_min_max": [min(rank_ms), max(rank_ms)],
+                # every rank's GPU right after the timed steps (amdgpu hwmon: power1_average, freq1_input): ranks under
+                # different power caps / clocks show up here before they show up as a scaling loss
+                "rank_power_w_min_max": ([min(p for p, _ in rank_sensors), max(p for p, _ in rank_sensors)]
+                                         if all(p == p for p, _ in rank_sensors) else None),
+                "rank_sclk_mhz_min_max": ([min(c for _, c in rank_sensors), max(c for _, c in rank_sensors)]
+                                          if all(c == c for _, c in rank_sensors) else None),
+                "rccl_transport": (rccl_transport_summary(rccl_log)
+                                   if (rccl_log and world > 1 and torch.distributed.get_backend() == "nccl") else
+                                   ({"backend": torch.distributed.get_backend()} if world > 1 else None)),
                 "allreduce_ms_per_step": allreduce_ms,
                 "allreduce_bytes": 4 * flat.numel,
                 "pair_seeds_rank0": [100 * rank + i for i in range(a.pairs_per_gpu)],
@@ -684,8 +766,18 @@ def main():
             if "ref" in big:            # oracle result at the metric's size vs the HIP path on the same pair and weights
                 from tests.oracle_at_size import compare_with_hip
                 try:
-                    par = compare_with_hip(big.pop("ref"), dev)
+                    ref_big = big.pop("ref")
+                    par = compare_with_hip(ref_big, dev)
                     per, per_bb = par.pop("gradient_per_tensor"), par.pop("backbone_gradient_per_tensor")
+                    if a.conv != "f32":
+                        # the same comparison with the exact fp32-MFMA kernels: what is arithmetic (f16x3 split operands) and
+                        # what is implementation, separately in the line
+                        pf = compare_with_hip(ref_big, dev, mode="f32")
+                        for k in ("keypoints", "matrix", "grid", "warped", "mse", "gradient_rel_l2", "backbone_gradient_rel_l2",
+                                  "backbone_gradient_worst_tensor", "backbone_gradient_worst_rel_l2", "tail_rel_l2_hip"):
+                            if k in pf:
+                                par["f32_mode_" + k] = pf[k]
+                    del ref_big
                     par["backbone_gradient_tensors_above_1e-3"] = {k: round(v, 6) for k, v in per_bb.items() if v > 1e-3}
                     par["gradient_notes"] = ("gradient_rel_l2: loss.backward() end to end; backbone_gradient_rel_l2: the "
                                              "backbone's backward alone, HIP and oracle on the SAME d(loss)/d(keypoints); "

@@ -102,14 +102,24 @@ def _grad_table(named_params, ref_grads):
     return (num / den) ** 0.5, per
 
 
-def compare_with_hip(ref, dev="cuda"):
+def compare_with_hip(ref, dev="cuda", mode=None, extras=True):
     """The HIP path (the bench's train step minus the optimizer) on `ref`'s pair and weights.  Returns max-abs differences of
     keypoints / matrix / grid / warped volume, |MSE difference|, and relative-L2 gradient differences:
       gradient_rel_l2            end to end (HIP loss.backward() vs the oracle's), whole vector + per tensor;
       backbone_gradient_rel_l2   the backbone's backward alone: HIP and oracle given the SAME cotangent d(loss)/d(keypoints)
                                  (the oracle's fp32 one);
-      tail_rel_l2_{hip,oracle}   d(loss)/d(keypoints) of each against the fp64 tail."""
-    from keymorph_amd import ops
+      tail_rel_l2_{hip,oracle}   d(loss)/d(keypoints) of each against the fp64 tail.
+    mode: run the comparison under another convolution arithmetic (backbone_ops.set_conv_mode), restored afterwards."""
+    from keymorph_amd import backbone_ops, ops
+    if mode is not None:
+        # another arithmetic of the 27-tap / 1x1x1 kernels ("f32": the exact fp32 MFMA) on the same pair: separates what the
+        # split-operand arithmetic contributes from what the implementation does (no forward-only extra legs)
+        old_mode = backbone_ops.CONV_MODE
+        backbone_ops.set_conv_mode(mode)
+        try:
+            return compare_with_hip(ref, dev, mode=None, extras=False)
+        finally:
+            backbone_ops.set_conv_mode(old_mode)
     tt, K = ref["transform"], ref["keypoints"]
     km = hip_model(ref["sd"], K, dev)
     f, m = ref["img_f"].to(dev), ref["img_m"].to(dev)
@@ -144,7 +154,8 @@ def compare_with_hip(ref, dev="cuda"):
     wb = max(per_bb, key=per_bb.get)
     out.update({"backbone_gradient_rel_l2": bb, "backbone_gradient_worst_tensor": wb,
                 "backbone_gradient_worst_rel_l2": per_bb[wb], "backbone_gradient_per_tensor": per_bb})
-    out.update(extra_legs(ref, km, f, m, dev))
+    if extras:
+        out.update(extra_legs(ref, km, f, m, dev))
     del km
     torch.cuda.empty_cache()
     return out
@@ -237,3 +248,63 @@ def oracle_convnet(size, keypoints, sd_seed=77, vol_seed=11, cot_seed=4, threads
     (pts * cot).sum().backward()
     return {"x": x, "sd": {k: v.detach() for k, v in sd.items()}, "y": y.detach(), "pts": pts.detach(), "cot": cot,
             "grads": {k: v.grad.detach() for k, v in sd.items()}}
+
+
+def oracle_backbone_fp64(size, keypoints, sd_seed=23, vol_seed=100, cot_seed=6, threads=32, in_subprocess=True):
+    """The BACKBONE's backward (image -> TruncatedUNet3D -> center of mass, keymorph/model.py:111-117) for one blob volume and
+    one seeded cotangent d(loss)/d(keypoints), by the oracle's autograd in fp32 (the reference arithmetic) AND in fp64 (truth)
+    from the same fp32 weights and image: who is closer to the truth, tensor by tensor, when the HIP path and the fp32 oracle
+    disagree.  ~12 GB and under a minute at 128^3 / 512 keypoints; child process by default (see oracle_pair)."""
+    if in_subprocess:
+        return _child(f"oracle_backbone_fp64({size}, {keypoints}, {sd_seed}, {vol_seed}, {cot_seed}, {threads}, False)", threads)
+    from keymorph_amd import synthetic
+    from oracle import keymorph_oracle as O
+    x = synthetic.blob_volume(size, vol_seed, torch.device("cpu"))
+    sd0 = seeded_state_dict(unet_shapes(keypoints, 32, trunc=1), sd_seed)
+    cot = torch.randn(1, keypoints, 3, generator=torch.Generator().manual_seed(cot_seed))
+    out = {"x": x, "sd": sd0, "cot": cot}
+    for name, dt in (("fp32", torch.float32), ("fp64", torch.float64)):
+        sd = {k: v.detach().to(dt).clone().requires_grad_(True) for k, v in sd0.items()}
+        pts = O.center_of_mass(O.unet3d_forward(sd, x.to(dt), 4, 1, 8), "ij")
+        (pts * cot.to(dt)).sum().backward()
+        out["pts_" + name] = pts.detach()
+        out["grads_" + name] = {k: v.grad.detach() for k, v in sd.items()}
+    return out
+
+
+def oracle_tps_step(size, keypoints, lam, sd_seed=23, seed=100, threads=32, in_subprocess=True):
+    """ONE training step with a TPS transform (scripts/train.py:129-176: KeyMorph.forward with `tps_<lam>`, align_img, MSELoss,
+    loss.backward()) by the oracle's autograd on the host: the grid evaluation is chunked over z slabs under
+    torch.utils.checkpoint (the reference's own `use_checkpoint` / subgrid device for the (K, N, 3) temporaries,
+    keymorph/keypoint_aligners.py:365-433).  Returns the pair, the weights, loss, keypoints, grid samples and every parameter
+    gradient."""
+    if in_subprocess:
+        return _child(f"oracle_tps_step({size}, {keypoints}, {lam}, {sd_seed}, {seed}, {threads}, False)", threads)
+    from torch.utils.checkpoint import checkpoint
+    from keymorph_amd import synthetic
+    from oracle import keymorph_oracle as O
+    cpu = torch.device("cpu")
+    img_f = synthetic.blob_volume(size, seed, cpu)
+    g = O.affine_grid(torch.inverse(synthetic.random_affine_matrix(seed, cpu)), (size,) * 3)
+    img_m = O.align_img(g, img_f)
+    sd = {k: v.requires_grad_(True) for k, v in seeded_state_dict(unet_shapes(keypoints, 32, trunc=1), sd_seed).items()}
+    pf = O.center_of_mass(O.unet3d_forward(sd, img_f, 4, 1, 8), "ij")
+    pm = O.center_of_mass(O.unet3d_forward(sd, img_m, 4, 1, 8), "ij")
+    lm = torch.full((1,), float(lam))
+    theta = O.tps_fit(pf, pm, lm)                                               # ctrl = points_f, tgt = points_m: the inverse map
+    base = O.base_grid((size,) * 3)                                             # (D, H, W, 3) ij
+    slabs = []
+    for z0 in range(0, size, 8):
+        pts = base[z0:z0 + 8].reshape(1, -1, 3)
+        slabs.append(checkpoint(lambda th, c, p: O.tps_transform_points(th, c, p), theta, pf, pts, use_reentrant=False)
+                     .reshape(1, -1, size, size, 3))
+    grid = torch.cat(slabs, dim=1).flip(-1)
+    img_a = O.align_img(grid, img_m)
+    loss = O.mse_loss(img_f, img_a)
+    loss.backward()
+    gen = torch.Generator().manual_seed(5)
+    idx = [torch.randint(0, size, (4096,), generator=gen) for _ in range(3)]
+    return {"img_f": img_f, "img_m": img_m, "sd": {k: v.detach() for k, v in sd.items()},
+            "grads": {k: v.grad.detach() for k, v in sd.items()}, "loss": float(loss.detach()), "points_f": pf.detach(),
+            "points_m": pm.detach(), "idx": idx, "grid_samples": grid.detach()[0][idx[0], idx[1], idx[2]],
+            "size": size, "keypoints": keypoints, "lam": float(lam)}

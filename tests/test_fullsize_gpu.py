@@ -478,7 +478,12 @@ def test_fullsize_vs_oracle_256_affine():
         print(f"   backbone-only grad {k:60s} rel-L2 {v:.2e}   (end to end {per[k]:.2e})")
     assert par["keypoints"] <= 1e-4 and par["matrix"] <= 1e-4 and par["grid"] <= 1e-4 and par["warped"] <= 1e-4, par
     assert par["mse"] <= 1e-6, par
-    assert par["backbone_gradient_rel_l2"] <= 2e-3 and max(per_bb.values()) <= 1e-2, (par, per_bb)
+    # (round 5, after the fp64 comparison at 128^3 -- test_backbone_backward_vs_fp64_oracle_128 -- said who is off where: the
+    # whole vector and every tensor outside the first encoder block are held to half of round 4's bars; the first block's
+    # cancelling sums -- 6.7e-3 on its one-element GroupNorm weight here, the 22-bit operands' doing -- keep 1e-2)
+    assert par["backbone_gradient_rel_l2"] <= 1e-3, par
+    assert max(v for k, v in per_bb.items() if not k.startswith("encoders.0.")) <= 3e-3, per_bb
+    assert max(per_bb.values()) <= 1e-2, per_bb
     assert par["tail_rel_l2_hip"] <= max(1e-4, 1.25 * par["tail_rel_l2_oracle"]), par
     assert par["gradient_rel_l2"] <= 2e-3 + 2 * (par["tail_rel_l2_hip"] + par["tail_rel_l2_oracle"]), par
 
@@ -489,3 +494,82 @@ def test_fullsize_vs_oracle_256_affine():
     # fp64 truth than 1.25 x the reference arithmetic's own fp32 error (or 1e-4)
     assert par["tps_0_grid_vs_fp64"] <= max(1e-4, 1.25 * par["tps_0_oracle_fp32_vs_fp64"]), par
     assert par["dice_fused"] <= 1e-4 and par["dice_unfused"] <= 1e-4, par
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: who is right when the HIP backward and the oracle's fp32 autograd disagree?  The backbone's backward against an
+# fp64 run of the oracle at 128^3 / 512 keypoints (tests/oracle_at_size.py::oracle_backbone_fp64).
+# ---------------------------------------------------------------------------------------------------------------------
+def test_backbone_backward_vs_fp64_oracle_128():
+    """image -> TruncatedUNet3D(f_maps 32, 4 levels, 1 truncated) -> center of mass (keymorph/model.py:111-117), one seeded
+    cotangent: every parameter-gradient tensor of the HIP path against the oracle's FP64 autograd (truth), next to the
+    oracle's own fp32 autograd (the reference arithmetic).  Bar per tensor: |hip - fp64| <= max(1e-3, 1.25 |oracle fp32 -
+    fp64|) relative L2; the whole vector <= 5e-4 (measured: hip 3.3e-4, oracle fp32 3.8e-4 -- closer than the reference
+    arithmetic overall).  The exception, measured and bounded separately: the FIRST encoder block's tensors, sums over 2 M
+    voxels that cancel to ~1e-4 of their terms.  There the HIP path is the one further from the truth -- first GroupNorm
+    (bias, weight) 4.9e-3 / 4.6e-3 where the reference arithmetic is 1.0e-3 / 1.4e-3 -- and the cause is the split-operand
+    arithmetic's 22 significant bits: tools/diag_backbone_fp64.py gives 2.0e-3 / 2.1e-3 with bf16x6 (24 bits) and
+    3.9e-4 / 5.7e-4 with the exact fp32 MFMA, unchanged by the statistics fold, the lazy first layer or the fused pooling.
+    Bar for those: 8e-3."""
+    from tests.oracle_at_size import hip_model, oracle_backbone_fp64
+    if _host_ram_gib() < 48:
+        pytest.skip("needs ~12 GB of host RAM for the fp64 autograd graph at 128^3")
+    S, Kk = 128, 512
+    ref = oracle_backbone_fp64(S, Kk)
+    km = hip_model(ref["sd"], Kk, DEV)
+    pts = km.get_keypoints(ref["x"].to(DEV))
+    assert float((pts.detach().cpu().double() - ref["pts_fp64"]).abs().max()) <= 1e-5
+    torch.autograd.backward([pts], [ref["cot"].to(DEV)])
+    g64, g32 = ref["grads_fp64"], ref["grads_fp32"]
+    rows, num_h, num_o, den = [], 0.0, 0.0, 0.0
+    for k, p in km.backbone.named_parameters():
+        t = g64[k].double()
+        eh = float((p.grad.detach().cpu().double() - t).norm() / (t.norm() + 1e-300))
+        eo = float((g32[k].double() - t).norm() / (t.norm() + 1e-300))
+        rows.append((k, eh, eo))
+        num_h += float((p.grad.detach().cpu().double() - t).pow(2).sum())
+        num_o += float((g32[k].double() - t).pow(2).sum())
+        den += float(t.pow(2).sum())
+    whole_h, whole_o = (num_h / den) ** 0.5, (num_o / den) ** 0.5
+    print(f"backbone backward vs fp64 at 128^3 / 512 kp: whole vector hip {whole_h:.2e}, oracle fp32 {whole_o:.2e}")
+    for k, eh, eo in sorted(rows, key=lambda r: -max(r[1], r[2]))[:8]:
+        print(f"   {k:62s} hip {eh:.2e}   oracle fp32 {eo:.2e}   closer: {'hip' if eh <= eo else 'oracle'}")
+    first_block = lambda k: k.startswith("encoders.0.")      # noqa: E731
+    worse = [(k, eh, eo) for k, eh, eo in rows if eh > (8e-3 if first_block(k) else max(1e-3, 1.25 * eo))]
+    assert not worse, worse
+    assert whole_h <= 5e-4, (whole_h, whole_o)
+
+
+def test_tps_training_step_vs_oracle_autograd_64_k512():
+    """ONE training step with a TPS transform and the production kernel variants that do not need a large volume -- K = 512
+    keypoints, so the workgroup-cluster LU and the row-hoisted T = 512 grid evaluators run, forward AND backward -- against
+    the oracle's autograd of the same step (scripts/train.py:129-176; keymorph/keypoint_aligners.py:276-433 chunked under
+    torch.utils.checkpoint): 64^3 pair, tps_1.  Loss <= 1e-6, keypoints / sampled grid <= 1e-4, whole parameter-gradient
+    vector <= 5e-3 relative L2 (a random-init backbone clumps its keypoints: the TPS tail amplifies fp32 rounding of the
+    keypoints 100-300x)."""
+    from keymorph_amd import ops
+    from tests.oracle_at_size import hip_model, oracle_tps_step
+    S, Kk, lam = 64, 512, 1.0
+    ref = oracle_tps_step(S, Kk, lam)
+    km = hip_model(ref["sd"], Kk, DEV)
+    f, m = ref["img_f"].to(DEV), ref["img_m"].to(DEV)
+    tt = "tps_1"
+    r = km(f, m, transform_type=tt, return_aligned_points=False)[tt]
+    loss, _ = ops.warp_mse(m, r["grid"], f)
+    loss.backward()
+    i0, i1, i2 = (t.to(DEV) for t in ref["idx"])
+    e_pts = max(float((r["points_f"].detach().cpu() - ref["points_f"]).abs().max()),
+                float((r["points_m"].detach().cpu() - ref["points_m"]).abs().max()))
+    e_grid = float((r["grid"].detach()[0][i0, i1, i2].cpu() - ref["grid_samples"]).abs().max())
+    e_loss = abs(float(loss.detach()) - ref["loss"])
+    num = den = 0.0
+    per = {}
+    for k, p in km.backbone.named_parameters():
+        a, b = p.grad.detach().cpu().double(), ref["grads"][k].double()
+        per[k] = float((a - b).norm() / (b.norm() + 1e-300))
+        num += float((a - b).pow(2).sum()); den += float(b.pow(2).sum())
+    whole = (num / den) ** 0.5
+    print(f"tps_1 training step 64^3 / 512 kp vs oracle autograd: keypoints {e_pts:.2e} grid {e_grid:.2e} loss {e_loss:.2e} "
+          f"gradient {whole:.2e}; worst tensors {sorted(per.items(), key=lambda kv: -kv[1])[:3]}")
+    assert e_pts <= 1e-4 and e_grid <= 1e-4 and e_loss <= 1e-6, (e_pts, e_grid, e_loss)
+    assert whole <= 3e-3, (whole, sorted(per.items(), key=lambda kv: -kv[1])[:5])      # measured 1.0e-3
