@@ -545,7 +545,7 @@ def test_tps_training_step_vs_oracle_autograd_64_k512():
     keypoints, so the workgroup-cluster LU and the row-hoisted T = 512 grid evaluators run, forward AND backward -- against
     the oracle's autograd of the same step (scripts/train.py:129-176; keymorph/keypoint_aligners.py:276-433 chunked under
     torch.utils.checkpoint): 64^3 pair, tps_1.  Loss <= 1e-6, keypoints / sampled grid <= 1e-4, whole parameter-gradient
-    vector <= 5e-3 relative L2 (a random-init backbone clumps its keypoints: the TPS tail amplifies fp32 rounding of the
+    vector <= 3e-3 relative L2 (a random-init backbone clumps its keypoints: the TPS tail amplifies fp32 rounding of the
     keypoints 100-300x)."""
     from keymorph_amd import ops
     from tests.oracle_at_size import hip_model, oracle_tps_step
