@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--also-f32", type=int, default=3,
                     help="N > 0: also time N steps with the exact fp32-MFMA convolutions (v_mfma_f32_32x32x2_f32) and "
                          "report them as f32_mfma_* next to the f16x3 headline (N = 1 rank only)")
+    ap.add_argument("--amp", type=int, default=3,
+                    help="N > 0: also time N steps with KeyMorph(use_amp=True) -- the one-product fp16 backbone "
+                         "(keymorph/model.py:176-191) -> amp_pairs_per_s, amp_roofline against 2.5 PFLOP/s; never the headline")
     ap.add_argument("--dice", type=int, default=3,
                     help="N > 0: also time N steps of the Dice branch (scripts/train.py:146-164: a 14-class one-hot "
                          "segmentation warped with the same grid + DiceLoss as the loss) -> dice_pairs_per_s")
@@ -469,6 +472,35 @@ def main():
         extra.update({"f32_mfma_ms_per_step": 1000 * dt_f, "f32_mfma_pairs_per_s": a.pairs_per_gpu * world / dt_f,
                       "f32_mfma_note": f"same step with KEYMORPH_HIP_CONV=f32 (v_mfma_f32_32x32x2_f32, no operand "
                                        f"splitting), {a.also_f32} timed step(s)"})
+    if a.amp > 0 and a.conv == "f16x3":      # use_amp=True: the one-product fp16 backbone, in the same driver run
+        model.use_amp = True
+        timed(1)
+        dt_a, loss_a = timed(a.amp)
+        _lib.profiler.reset()
+        _lib.profiler.enabled = True
+        train_step(model, flat, opt, img_f, img_m, tt)
+        pa = _lib.profiler.summary()
+        _lib.profiler.enabled = False
+        _lib.profiler.reset()
+        model.use_amp = False
+        backbone_ops.set_amp(False)
+        ca = {"ms": 0.0, "flops": 0.0}
+        for nm in ("kmh_conv3d_fwd_bf", "kmh_conv3d_fwd_bf_pool"):
+            for k in ca:
+                ca[k] += pa.get(nm, {}).get(k, 0)
+        amp_tf = ca["flops"] / max(ca["ms"], 1e-9) / 1e9
+        extra.update({"amp_pairs_per_s": a.pairs_per_gpu * world / dt_a, "amp_ms_per_step": 1000 * dt_a, "amp_loss": loss_a,
+                      "amp_roofline": {"bound": "mfma", "achieved": amp_tf, "peak": 2500.0, "unit": "TFLOP/s",
+                                       "frac": amp_tf / 2500.0,
+                                       "what": "27-tap forward / data-gradient family under use_amp: algorithmic flops / HIP-event "
+                                               "time against the dense fp16 MFMA peak (one product per block)"},
+                      "amp_wgrad_tflops": pa.get("kmh_conv3d_wgrad_bf", {}).get("flops", 0) /
+                                          max(pa.get("kmh_conv3d_wgrad_bf", {}).get("ms", 0), 1e-9) / 1e9,
+                      "amp_note": f"KeyMorph(use_amp=True) (keymorph/model.py:176-191 autocasts the extractor to fp16): the 27-tap "
+                                  f"forward / data-gradient kernels, the weight gradient and the fused decoder operator multiply "
+                                  f"fp16 hi terms only (fp32 accumulation and tensors); first layer, head, aligner, warp and loss "
+                                  f"unchanged; {a.amp} timed step(s); NOT the headline (a reduced-precision configuration)"})
+
     def agree(ok):
         """True iff every rank says ok (one MIN all-reduce; ranks must reach this together)"""
         if world == 1:

@@ -203,6 +203,12 @@ int kmh_conv3d_fwd_bf(const float* x, const float* scale, const float* shift, co
  * 2: conv3_fwd_g_kernel whenever its preconditions hold (parity tests on small / ragged volumes).  Returns the
  * previous mode, -22 for a bad argument. */
 int kmh_conv3d_fwd_bf_set_dispatch(int mode);
+/* use_amp (keymorph/model.py:176-191 autocasts the keypoint extractor to fp16): on = 1 makes the split-operand kernels of the
+ * 27-tap forward / data gradient (one-wave kernels), the wave-specialised weight gradient and the fused decoder operator
+ * multiply only the fp16 hi terms -- fp16 inputs, fp32 accumulation, one MFMA per product block instead of three (terms = 2
+ * calls only; packing, scales and layouts are unchanged).  Process-wide, KEYMORPH_AMP sets the initial value; returns the
+ * previous setting. */
+int kmh_conv_set_amp(int on);
 /* in_blocked of kmh_conv3d_fwd_bf: 0 = x is (N,D,H,W,Cin); 1 = channel-blocked (N,Cin/8,D,H,W,8) fp32; 2 = PRE-SPLIT
  * channel-blocked: (N, Cin/8, D*H*W + 1) records of 32 bytes, the 8 fp16 "hi" then the 8 fp16 "lo" terms of fmaf(value, S, 0)
  * with S = ascale[0], record D*H*W of every plane zero -- what kmh_maxpool3d_bwd_split writes; the kernel then copies

@@ -67,6 +67,7 @@ PROTOS = {
     "kmh_conv3d_pack_weight_bf": (_i, [_f, _f, _i, _i, _i, _i, _f, _f]),
     "kmh_conv3d_fwd_bf": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f]),
     "kmh_conv3d_fwd_bf_set_dispatch": (_i, [_i]),
+    "kmh_conv_set_amp": (_i, [_i]),
     "kmh_conv3d_fwd_bf_variant": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "kmh_conv3d_fwd_bf_pool_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "kmh_conv3d_fwd_bf_split_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),

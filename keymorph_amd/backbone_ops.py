@@ -37,6 +37,14 @@ def set_conv_mode(mode: str):
     CONV_MODE = mode
 
 
+def set_amp(on: bool) -> bool:
+    """use_amp of KeyMorph (keymorph/model.py:176-191): True = the 27-tap forward / data-gradient kernels, the weight gradient
+    and the fused decoder operator multiply only the fp16 hi terms of their (range-scaled) operands -- fp16 inputs, fp32
+    accumulation, one MFMA per product block instead of three.  Process-wide (the library's `kmh_conv_set_amp`); returns the
+    previous setting.  Only the default f16x3 mode has the variant."""
+    return bool(_lib.load().kmh_conv_set_amp(int(bool(on))))
+
+
 def _f32(shape, dev):
     return torch.empty(shape, dtype=torch.float32, device=dev)
 

@@ -131,6 +131,10 @@ __device__ __forceinline__ kmh_f32x16 mfma16(kmh_bf16x8 a, kmh_bf16x8 b, kmh_f32
   else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// use_amp (keymorph/model.py:176-191 runs the backbone under fp16 autocast): the ONE-product arithmetic of the split-operand
+// kernels -- operands range-scaled and split exactly as for f16x3, only hi x hi multiplied: fp16 inputs (11 significant bits),
+// fp32 accumulation, a third of the MFMA work.  Process-wide switch (kmh_conv_set_amp); kernels are instantiated with AMP = true.
+bool kmh_amp_enabled();
 // 8 floats -> TERMS fragments (8 x 16 bit each)
 // two values -> TERMS packed 16-bit pairs (lo half = first value): one packed conversion per term
 template <int TERMS>

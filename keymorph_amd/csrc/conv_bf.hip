@@ -934,7 +934,7 @@ static_assert(GPL <= S_PLANE && GTZ == 4 && GTY == S_MR, "wave = plane, 8 rows")
 // (x, y)-pooled partials through LDS); ATen's first-max rule, the same winners, the same outputs bit for bit.  What it buys:
 // the plain one-wave kernel spends 38 % of a two-chunk 16 -> 32 brick in its epilogue storing 128 KB (cycle stamps, r5a); the
 // pooled tensor is 16 KB.
-template <int NT, bool ZP = false, bool SPLIT = false, bool POOL = false>
+template <int NT, bool ZP = false, bool SPLIT = false, bool POOL = false, bool AMP = false>
 __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16x8* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int D, int H, int W, int Cin,
@@ -1106,14 +1106,16 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   const long long step_stride = 2ll * CoutP, term_stride = (long long)NST * step_stride;
   bf16x8 bq[BD][NT][TERMS];
   long long o0 = 0;
+  // (AMP: the lo fragments are never multiplied and must not even be requested -- an asm load whose destination the compiler
+  // sees as dead lands LATER in a register it has meanwhile given to something else)
   auto b_issue = [&](int slot) {
     const bf16x8* p0 = wp + o0;
     const bf16x8* p1 = p0 + term_stride;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[slot][0][0]) : "v"(p0) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[slot][0][1]) : "v"(p1) : "memory");
+    if (!AMP) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[slot][0][1]) : "v"(p1) : "memory");
     if (NT == 2) {
       asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(bq[slot][NT - 1][0]) : "v"(p0) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(bq[slot][NT - 1][1]) : "v"(p1) : "memory");
+      if (!AMP) asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(bq[slot][NT - 1][1]) : "v"(p1) : "memory");
     }
     o0 += step_stride;
   };
@@ -1238,7 +1240,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
         if (!SPLIT && s >= 2 && s < 10) convert1(nch, cv_next, pb ^ 1, s - 2, rawq[(s - 2) % 2][0], rawq[(s - 2) % 2][1]);
         // term-major over the 8 x NT accumulators: per accumulator the order of conv3_fwd_bf_kernel (smallest terms first)
 #pragma unroll
-        for (int q3 = 0; q3 < 3; ++q3)
+        for (int q3 = AMP ? 2 : 0; q3 < 3; ++q3)       // (AMP: hi x hi only)
 #pragma unroll
           for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -1251,7 +1253,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
           __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, KMH_S_LEAD, 0);
 #pragma unroll
-          for (int k = 0; k < MR * NT * 3 - KMH_S_LEAD; ++k) {
+          for (int k = 0; k < MR * NT * (AMP ? 1 : 3) - KMH_S_LEAD; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x002, KMH_S_VPM, 0);     // a few of the conversion's VALU ...
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // ... one MFMA
           }
@@ -1451,6 +1453,27 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   }
 }
 
+static std::atomic<int> g_amp{-1};
+}  // namespace
+bool kmh_amp_enabled() {
+  int v = g_amp.load(std::memory_order_relaxed);
+  if (v < 0) {
+    v = (getenv("KEYMORPH_AMP") && atoi(getenv("KEYMORPH_AMP")) != 0) ? 1 : 0;
+    g_amp.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+/* use_amp: 1 = the split-operand kernels of the 27-tap forward / data gradient (one-wave kernels), the wave-specialised weight
+ * gradient and the fused decoder operator multiply only the hi terms (fp16 inputs, fp32 accumulation: one MFMA per product
+ * block instead of three); 0 = f16x3 (default; KEYMORPH_AMP sets the initial value).  Process-wide; returns the previous
+ * setting.  The first layer, the head, the aligners, the warp and the losses are unaffected (the reference's autocast,
+ * keymorph/model.py:176-191, also leaves everything after the keypoints in fp32). */
+KMH_API int kmh_conv_set_amp(int on) {
+  const int old = kmh_amp_enabled() ? 1 : 0;
+  g_amp.store(on ? 1 : 0, std::memory_order_relaxed);
+  return old;
+}
+namespace {
 static inline int cout_pad(int Cout) { return Cout > 64 ? (Cout + 127) & ~127 : (Cout + 63) & ~63; }
 static inline bool use_zpair(int Cout) { return Cout <= 16; }
 
@@ -1509,7 +1532,7 @@ __global__ __launch_bounds__(256) void pack_weight_up_kernel(const float* __rest
   }
 }
 
-template <int TERMS>
+template <int TERMS, bool AMP = false>
 __global__ __launch_bounds__(UP_TPB, 2) void conv3_up2_fwd_kernel(
     const float* __restrict__ xl, const float* __restrict__ scale, const float* __restrict__ shift, int Ctot, int cofs,
     const bf16x8* __restrict__ wp, float* __restrict__ y, int Dl, int Hl, int Wl, int Cl, int Cout, int CoutP,
@@ -1619,8 +1642,10 @@ __global__ __launch_bounds__(UP_TPB, 2) void conv3_up2_fwd_kernel(
           acc[pl][m] = mfma16<TERMS>(a[1], b[1], acc[pl][m]);
           acc[pl][m] = mfma16<TERMS>(a[0], b[2], acc[pl][m]);
         }
-        acc[pl][m] = mfma16<TERMS>(a[1], b[0], acc[pl][m]);
-        acc[pl][m] = mfma16<TERMS>(a[0], b[1], acc[pl][m]);
+        if constexpr (!AMP) {
+          acc[pl][m] = mfma16<TERMS>(a[1], b[0], acc[pl][m]);
+          acc[pl][m] = mfma16<TERMS>(a[0], b[1], acc[pl][m]);
+        }
         acc[pl][m] = mfma16<TERMS>(a[0], b[0], acc[pl][m]);
       }
     }
@@ -1705,7 +1730,7 @@ __global__ __launch_bounds__(256) void pack_weight_upt_kernel(const float* __res
   }
 }
 
-template <int TERMS>
+template <int TERMS, bool AMP = false>
 __global__ __launch_bounds__(DUP_TPB, TERMS == 2 ? 2 : 3) void conv3_up2_dgrad_kernel(
     const float* __restrict__ dz /* (N,2Dl,2Hl,2Wl,Cout) */, const bf16x8* __restrict__ wp,
     float* __restrict__ ds /* (N,Dl,Hl,Wl,Cl) */, int Dl, int Hl, int Wl, int Cl, int CiP, int Cout, int tiles_x,
@@ -1819,8 +1844,10 @@ __global__ __launch_bounds__(DUP_TPB, TERMS == 2 ? 2 : 3) void conv3_up2_dgrad_k
             acc[m] = mfma16<TERMS>(a[1], b[1], acc[m]);
             acc[m] = mfma16<TERMS>(a[0], b[2], acc[m]);
           }
-          acc[m] = mfma16<TERMS>(a[1], b[0], acc[m]);
-          acc[m] = mfma16<TERMS>(a[0], b[1], acc[m]);
+          if constexpr (!AMP) {
+            acc[m] = mfma16<TERMS>(a[1], b[0], acc[m]);
+            acc[m] = mfma16<TERMS>(a[0], b[1], acc[m]);
+          }
           acc[m] = mfma16<TERMS>(a[0], b[0], acc[m]);
         }
       }
@@ -1861,7 +1888,7 @@ __global__ __launch_bounds__(DUP_TPB, TERMS == 2 ? 2 : 3) void conv3_up2_dgrad_k
 // 128 x 256 tile on 8 waves (1.33x the intensity) needs 176 registers = ONE workgroup per CU and is no faster (2.97 vs 2.86 ms).
 constexpr int GK = 32;                        // voxels per staging step (64: two workgroups per CU, 5 % slower)
 constexpr int GPITCH = GK * 2 + 16;           // bytes per LDS row (32 x 2 B + pad: 5 x 16 B, conflict-free b128 reads)
-template <int TERMS>
+template <int TERMS, bool AMP = false>
 __global__ __launch_bounds__(256, 3) void up2_wgrad_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                 float* __restrict__ Cp, int V, int Cl, int J, int kslab,
                                                                 int ntn, int ntm, const float* __restrict__ ascale,
@@ -1973,8 +2000,10 @@ __global__ __launch_bounds__(256, 3) void up2_wgrad_gemm_kernel(const float* __r
             acc[i][j] = mfma16<TERMS>(a[i][1], b[j][1], acc[i][j]);
             acc[i][j] = mfma16<TERMS>(a[i][0], b[j][2], acc[i][j]);
           }
-          acc[i][j] = mfma16<TERMS>(a[i][1], b[j][0], acc[i][j]);
-          acc[i][j] = mfma16<TERMS>(a[i][0], b[j][1], acc[i][j]);
+          if constexpr (!AMP) {
+            acc[i][j] = mfma16<TERMS>(a[i][1], b[j][0], acc[i][j]);
+            acc[i][j] = mfma16<TERMS>(a[i][0], b[j][1], acc[i][j]);
+          }
           acc[i][j] = mfma16<TERMS>(a[i][0], b[j][0], acc[i][j]);
         }
     }
@@ -2037,6 +2066,9 @@ KMH_API int kmh_up2_wgrad_gemm(const float* A, const float* B, float* C, int N, 
   dim3 g(ntn * ntm * ns, 1, N);
   static const int xcd = getenv("KEYMORPH_UP2_GEMM_NO_XCD") ? 0 : 1;
   if (terms == 2)
+    if (kmh_amp_enabled())
+      up2_wgrad_gemm_kernel<2, true><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale, a_scale, a_shift, xcd);
+    else
     up2_wgrad_gemm_kernel<2><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale, a_scale, a_shift, xcd);
   else
     up2_wgrad_gemm_kernel<3><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale, a_scale, a_shift, xcd);
@@ -2082,6 +2114,9 @@ KMH_API int kmh_conv3d_up2_dgrad(const float* dz, const void* packed, float* ds,
   hipStream_t s = (hipStream_t)stream;
   double* sp = stats_out ? (double*)stats_ws : nullptr;
   if (terms == 2)
+    if (kmh_amp_enabled())
+      conv3_up2_dgrad_kernel<2, true><<<g, DUP_TPB, 0, s>>>(dz, (const bf16x8*)packed, ds, Dl, Hl, Wl, Cl, CiP, Cout, tx, ty, dscale, wscale, sp, in_blocked);
+    else
     conv3_up2_dgrad_kernel<2><<<g, DUP_TPB, 0, s>>>(dz, (const bf16x8*)packed, ds, Dl, Hl, Wl, Cl, CiP, Cout, tx, ty, dscale, wscale, sp, in_blocked);
   else
     conv3_up2_dgrad_kernel<3><<<g, DUP_TPB, 0, s>>>(dz, (const bf16x8*)packed, ds, Dl, Hl, Wl, Cl, CiP, Cout, tx, ty, dscale, wscale, sp, in_blocked);
@@ -2123,6 +2158,10 @@ KMH_API int kmh_conv3d_up2_fwd(const float* xl, const float* scale, const float*
   dim3 g(tx * ty * Dl * ceil_div(Cout, 64), 1, N);
   hipStream_t s = (hipStream_t)stream;
   if (terms == 2)
+    if (kmh_amp_enabled())
+      conv3_up2_fwd_kernel<2, true><<<g, UP_TPB, 0, s>>>(xl, scale, shift, Ctot, cofs, (const bf16x8*)packed, y, Dl, Hl, Wl, Cl,
+                                                Cout, CoutP, tx, ty, ascale, wscale);
+    else
     conv3_up2_fwd_kernel<2><<<g, UP_TPB, 0, s>>>(xl, scale, shift, Ctot, cofs, (const bf16x8*)packed, y, Dl, Hl, Wl, Cl,
                                                 Cout, CoutP, tx, ty, ascale, wscale);
   else
@@ -2227,6 +2266,14 @@ static int launch_fwd_s(const float* x, const float* scale, const float* shift, 
   static const bool tracing = getenv("KMH_G_TRACE") != nullptr;
   if (tracing && !trace) { if (hipMalloc(&trace, 240 * sizeof(long long)) != hipSuccess) trace = nullptr; }
   if (tracing && trace) (void)hipMemsetAsync(trace, 0, 240 * sizeof(long long), s);
+  if (kmh_amp_enabled()) {
+    e = hipFuncSetAttribute((const void*)conv3_fwd_s_kernel<NT, ZP, SPLIT, POOL, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            S_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    conv3_fwd_s_kernel<NT, ZP, SPLIT, POOL, true><<<dim3(wgs), S_TPB, S_LDS_BYTES, s>>>(
+        x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in, relu_out, tx, ty, tz, tzp, ascale, wscale,
+        stats_out ? stats_ws : nullptr, in_blocked, addend, total, N, tracing ? trace : nullptr, pool_arg);
+  } else
   conv3_fwd_s_kernel<NT, ZP, SPLIT, POOL><<<dim3(wgs), S_TPB, S_LDS_BYTES, s>>>(x, scale, shift, wp, bias, y, D, H, W, Cin, Cout, CoutP, relu_in,
                                                                relu_out, tx, ty, tz, tzp, ascale, wscale,
                                                                stats_out ? stats_ws : nullptr, in_blocked, addend, total, N,
@@ -2480,7 +2527,7 @@ __device__ __forceinline__ WgradTiles wgrad_deal_tiles(int CP, int MT, int TG, i
 //   1  the paired dealing's waves 0-4: tile 0 is kx = 0 (the words as read), tile 1 is kx = 1 of the SAME words
 //      (4 alignbyte); one LDS read feeds both
 //   2  the paired dealing's waves 5-7: both tiles are kx = 2, a pure register renaming (no VALU)
-template <int NT, int TERMS, int MODE = 0>
+template <int NT, int TERMS, int MODE = 0, bool AMP = false>
 __device__ __forceinline__ void wgrad_mfma_brick(const unsigned char* sXT, const unsigned char* sDT, int xt_bytes,
                                                  const WgradTiles& w, int ks, int KS, int li, int lh,
                                                  f32x16 (&acc)[MTWB][NT]) {
@@ -2552,8 +2599,10 @@ __device__ __forceinline__ void wgrad_mfma_brick(const unsigned char* sXT, const
           acc[j][t] = mfma16<TERMS>(a[j][1], b[t][1], acc[j][t]);
           acc[j][t] = mfma16<TERMS>(a[j][0], b[t][2], acc[j][t]);
         }
-        acc[j][t] = mfma16<TERMS>(a[j][1], b[t][0], acc[j][t]);
-        acc[j][t] = mfma16<TERMS>(a[j][0], b[t][1], acc[j][t]);
+        if constexpr (!AMP) {
+          acc[j][t] = mfma16<TERMS>(a[j][1], b[t][0], acc[j][t]);
+          acc[j][t] = mfma16<TERMS>(a[j][0], b[t][1], acc[j][t]);
+        }
         acc[j][t] = mfma16<TERMS>(a[j][0], b[t][0], acc[j][t]);
       }
   };
@@ -2858,7 +2907,7 @@ __device__ __forceinline__ void ws_barrier() {
 // 8 fp16 lo terms of fmaf(dz, S, 0) -- so a producer item (4 channels of two x neighbours) is four 8-byte loads and eight
 // 16-bit packs instead of two 16-byte loads, eight multiplies and four split_pair sequences: the same words in the same
 // transposed image, bit-identical sums.
-template <int NT, int TERMS, bool MASK, int PW, bool DSPLIT = false>
+template <int NT, int TERMS, bool MASK, int PW, bool DSPLIT = false, bool AMP = false>
 __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_wgrad_ws_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ dz, const float* __restrict__ dzmask, float* __restrict__ partial, int N, int D,
@@ -3120,7 +3169,7 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
     for (long long bi = b_beg; bi < b_end; ++bi) {
       const unsigned char* sXT = smemb + ((bi - b_beg) & 1) * buf_bytes;
       const unsigned char* sDT = sXT + TERMS * xt_bytes;
-      wgrad_mfma_brick<NT, TERMS, decltype(mode)::value>(sXT, sDT, xt_bytes, wt, ks, KS, li, lh, acc);
+      wgrad_mfma_brick<NT, TERMS, decltype(mode)::value, AMP>(sXT, sDT, xt_bytes, wt, ks, KS, li, lh, acc);
       if (bi + 1 < b_end) ws_barrier();                    // brick bi+1 is staged, stage (bi & 1) may be overwritten
     }
   };
@@ -3257,6 +3306,17 @@ static int launch_wgrad_ws(const WgradBfPlan& p, const float* x, const float* sc
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 g(p.ci_tiles * p.co_groups * p.nslab);
+  if constexpr (!MASK && PW == 8) {
+    if (kmh_amp_enabled()) {
+      e = hipFuncSetAttribute((const void*)conv3_wgrad_ws_kernel<NT, TERMS, MASK, PW, DSPLIT, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      conv3_wgrad_ws_kernel<NT, TERMS, MASK, PW, DSPLIT, true><<<g, 64 * (WS_CONS + PW), lds, s>>>(
+          x, scale, shift, dz, dzmask, ws, N, D, H, W, Cin, Cout, relu_in, p.CP, p.MT, p.TG, p.KS, p.ci_tiles, p.tiles_x, p.tiles_y,
+          p.tiles_z, p.bricks_per_slab, p.nslab, xscale, dscale, dz_blocked);
+      return KMH_LAUNCH_CHECK();
+    }
+  }
   conv3_wgrad_ws_kernel<NT, TERMS, MASK, PW, DSPLIT><<<g, 64 * (WS_CONS + PW), lds, s>>>(x, scale, shift, dz, dzmask, ws, N, D, H, W, Cin, Cout,
                                                                relu_in, p.CP, p.MT, p.TG, p.KS, p.ci_tiles, p.tiles_x,
                                                                p.tiles_y, p.tiles_z, p.bricks_per_slab, p.nslab, xscale,

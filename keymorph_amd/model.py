@@ -39,12 +39,12 @@ class KeyMorph(nn.Module):
             raise NotImplementedError("only the center-of-mass keypoint layer is implemented")
         self.keypoint_layer = CenterOfMass2d(indexing="ij") if dim == 2 else CenterOfMass3d(indexing="ij")
         self.max_train_keypoints = max_train_keypoints
-        self.use_amp = use_amp            # fp32 is the parity configuration; accepted for signature parity
-        if use_amp:
-            import warnings
-            warnings.warn("keymorph_amd: use_amp=True is accepted for signature parity and IGNORED -- the path computes "
-                          "fp32 results (split-fp16 matrix-core products, fp32 accumulation) whatever the flag says; the "
-                          "reference would autocast the keypoint extractor to fp16 (keymorph/model.py:176-191)")
+        # use_amp (keymorph/model.py:176-191: the reference runs the keypoint extractor under fp16 autocast): the one-product
+        # fp16 arithmetic of the backbone's matrix kernels -- fp16 inputs (11 significant bits), fp32 accumulation and fp32
+        # tensors, a third of the MFMA work -- instead of the fp32-class split-operand default.  The switch is process-wide
+        # (backbone_ops.set_amp) and is set by every call of get_keypoints(), so the backward of a step runs under the
+        # setting of its forward; aligners, warp and losses are fp32 either way, as in the reference.
+        self.use_amp = bool(use_amp)
         self.use_checkpoint = use_checkpoint
         self.max_rand_tps_lmbda = max_rand_tps_lmbda
         self.supported_transform_type = ["rigid", "affine", "tps"]
@@ -58,6 +58,9 @@ class KeyMorph(nn.Module):
     # ------------------------------------------------------------------
     def get_keypoints(self, img, return_feat=False):
         """model.py:111-117"""
+        if img.is_cuda:
+            from . import backbone_ops
+            backbone_ops.set_amp(self.use_amp)
         net = getattr(self.backbone, "module", self.backbone)   # nn.DataParallel wrapper (run.py:390)
         if (not return_feat and self.dim == 3 and hasattr(net, "keypoints_ij")
                 and (net.final_activation is None or net.training)):

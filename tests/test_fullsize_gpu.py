@@ -573,3 +573,39 @@ def test_tps_training_step_vs_oracle_autograd_64_k512():
           f"gradient {whole:.2e}; worst tensors {sorted(per.items(), key=lambda kv: -kv[1])[:3]}")
     assert e_pts <= 1e-4 and e_grid <= 1e-4 and e_loss <= 1e-6, (e_pts, e_grid, e_loss)
     assert whole <= 3e-3, (whole, sorted(per.items(), key=lambda kv: -kv[1])[:5])      # measured 1.0e-3
+
+
+def test_use_amp_one_product_backbone_vs_oracle_128():
+    """use_amp=True (keymorph/model.py:176-191: the reference autocasts the keypoint extractor to fp16): the one-product fp16
+    arithmetic of the 27-tap / weight-gradient / decoder kernels -- fp16 inputs, fp32 accumulation, fp32 tensors.  At 128^3 /
+    512 keypoints against the fp32 oracle: keypoints <= 2e-3, every gradient finite, whole gradient vector <= 5e-2 relative
+    L2; it is a different arithmetic from the default (results differ) and the default comes back when a use_amp=False model
+    runs (the switch is process-wide, set by every get_keypoints())."""
+    from keymorph_amd import backbone_ops as B
+    from tests.oracle_at_size import hip_model, oracle_backbone_fp64
+    if _host_ram_gib() < 48:
+        pytest.skip("needs ~12 GB of host RAM for the oracle's autograd graph at 128^3")
+    S, Kk = 128, 512
+    ref = oracle_backbone_fp64(S, Kk)
+    out = {}
+    try:
+        for amp in (True, False):
+            km = hip_model(ref["sd"], Kk, DEV)
+            km.use_amp = amp
+            pts = km.get_keypoints(ref["x"].to(DEV))
+            assert B.set_amp(amp) == amp                       # get_keypoints() set the library's switch
+            torch.autograd.backward([pts], [ref["cot"].to(DEV)])
+            num = den = 0.0
+            for k, p in km.backbone.named_parameters():
+                assert torch.isfinite(p.grad).all(), k
+                a, b = p.grad.detach().cpu().double(), ref["grads_fp32"][k].double()
+                num += float((a - b).pow(2).sum()); den += float(b.pow(2).sum())
+            out[amp] = (float((pts.detach().cpu() - ref["pts_fp32"]).abs().max()), (num / den) ** 0.5, pts.detach().clone())
+            del km
+    finally:
+        B.set_amp(False)
+    print(f"use_amp at 128^3 / 512 kp vs the fp32 oracle: keypoints {out[True][0]:.2e} (default {out[False][0]:.2e}), "
+          f"gradient {out[True][1]:.2e} (default {out[False][1]:.2e})")
+    assert out[True][0] <= 2e-3 and out[True][1] <= 5e-2, out[True][:2]
+    assert out[False][0] <= 1e-5 and out[False][1] <= 2e-3, out[False][:2]
+    assert not torch.equal(out[True][2], out[False][2]) and out[True][0] > 4 * out[False][0], "the one-product kernels did not run"

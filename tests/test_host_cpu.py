@@ -290,13 +290,16 @@ def test_f16x3_arithmetic_claim_emulated():
     assert e["f16x3_unscaled"] > 100 * e["f16x3"], e        # the tiny-gradient case: scaling is what makes it work
 
 
-def test_use_amp_is_accepted_but_warns():
-    """keymorph/model.py:176-191 autocasts the extractor under use_amp; this path is fp32-only and says so"""
-    import torch.nn as nn
+def test_use_amp_is_a_stored_flag_without_warning():
+    """keymorph/model.py:176-191 autocasts the extractor under use_amp; here the flag selects the one-product fp16 arithmetic
+    of the backbone's matrix kernels at every get_keypoints() call on a GPU tensor (tests/test_train_step_gpu.py); constructing
+    the model does not touch the library and does not warn"""
+    import warnings
     from keymorph_amd.model import KeyMorph
-    with pytest.warns(UserWarning, match="use_amp"):
-        km = KeyMorph(nn.Identity(), 4, 3, use_amp=True)
-    assert km.use_amp is True
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        km = KeyMorph(torch.nn.Identity(), 4, 3, use_amp=True)
+    assert km.use_amp is True and KeyMorph(torch.nn.Identity(), 4, 3).use_amp is False
 
 
 def test_flat_params_gathers_gradients():
