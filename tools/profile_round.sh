@@ -7,7 +7,7 @@ tag=${1:-rX}
 cd /tmp && export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
-B="python bench.py --no-cpu-baseline --also-f32 0 --dice 0 --eval-steps 0 --groupwise 0 --convnet 0 --sampler 0"
+B="python bench.py --no-cpu-baseline --also-f32 0 --amp 0 --dice 0 --eval-steps 0 --groupwise 0 --convnet 0 --sampler 0"
 python bench.py --steps 5 --warmup 2 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${tag} -o bench -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 python tools/rocpd_summary.py $(ls gpurun_out/prof_${tag}/*/*results.db gpurun_out/prof_${tag}/*results.db 2>/dev/null | head -1) --md gpurun_out/${tag}_kernel_trace_stats.md > /dev/null
