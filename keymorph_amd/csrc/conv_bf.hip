@@ -989,7 +989,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   };
 
   // LDS-DMA descriptors of a brick: 16-byte slot e = r * 256 + tid holds half (r >> 3) of halo voxel (r & 7) * 256 + tid
-  auto fill_offsets = [&](const Item& it) {
+  auto fill_offsets = [&](const Item& it) -> unsigned {      // -> bit i: voxel tid + 256 i of the halo is inside the volume
     const int x0 = it.bx * TX, y0 = it.by * GTY, z0 = it.bz * GTZ;
     int t_ = tid;
     asm volatile("" : "+v"(t_));
@@ -1004,31 +1004,25 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
         const bool in = (v < GPL) && ((unsigned)gx < (unsigned)W) && ((unsigned)gy < (unsigned)H) && ((unsigned)gz < (unsigned)D);
         sOff[r * S_TPB + t_] = in ? ((gz * H + gy) * W + gx) * KC : (int)vox * KC;      // read back by this thread only
       }
-      return;
+      return 0u;
     }
+    // ONE coordinate decode per halo voxel of the lane: both 16-byte halves' offsets and the voxel's inside bit (round 5: the
+    // table and inside_bits() used to decode the same voxels twice over, ~3k cycles of a brick's last stage and ~2k more
+    // after its epilogue)
+    unsigned bits = 0;
 #pragma unroll
-    for (int r = 0; r < S_NLD; ++r) {
-      const int e = r * S_TPB + t_, v0_ = (r & 7) * S_TPB + t_, v = v0_ < GPL ? v0_ : GPL - 1;
+    for (int r = 0; r < S_NCV; ++r) {
+      const int v0_ = r * S_TPB + t_, v = v0_ < GPL ? v0_ : GPL - 1;
       const int lx = v % HX, ly = (v / HX) % GHY, lz = v / (HX * GHY);
       int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - 1;
+      const bool in = (v0_ < GPL) && ((unsigned)gx < (unsigned)W) && ((unsigned)gy < (unsigned)H) && ((unsigned)gz < (unsigned)D);
+      bits |= (in ? 1u : 0u) << r;
       gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
       gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
       gz = gz < 0 ? 0 : (gz > D - 1 ? D - 1 : gz);
-      sOff[e] = ((gz * H + gy) * W + gx) * (in_blocked ? KC : Cin) + 4 * (r >> 3);      // read back by this thread only
-    }
-  };
-  auto inside_bits = [&](const Item& it) -> unsigned {     // bit i: voxel tid + 256 i of the halo is inside the volume
-    const int x0 = it.bx * TX, y0 = it.by * GTY, z0 = it.bz * GTZ;
-    unsigned bits = 0;
-    int t_ = tid;
-    asm volatile("" : "+v"(t_));
-#pragma unroll
-    for (int i = 0; i < S_NCV; ++i) {
-      const int v = t_ + i * S_TPB;
-      const int lx = v % HX, ly = (v / HX) % GHY, lz = v / (HX * GHY);
-      const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - 1;
-      const bool in = (v < GPL) && ((unsigned)gx < (unsigned)W) && ((unsigned)gy < (unsigned)H) && ((unsigned)gz < (unsigned)D);
-      bits |= (in ? 1u : 0u) << i;
+      const int off = ((gz * H + gy) * W + gx) * (in_blocked ? KC : Cin);
+      sOff[r * S_TPB + t_] = off;                 // read back by this thread only
+      sOff[(8 + r) * S_TPB + t_] = off + 4;
     }
     return bits;
   };
@@ -1132,14 +1126,13 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     if (trace && blockIdx.x == 0 && tid == 0 && tr_n < 240) trace[tr_n++] = __builtin_readcyclecounter();
   };
   // prologue: the first stage's halo, fetched and converted with nothing to hide behind
-  fill_offsets(cur);
-  unsigned cv_in = 0u;
+  unsigned cv_in = fill_offsets(cur);
+  unsigned cv_brick_next = 0u;                             // the NEXT brick's bits, formed with its table in its predecessor's last stage
   if constexpr (SPLIT) {
 #pragma unroll
     for (int p = 0; p < S_NLD; ++p) dma_piece(cur.n, 0, 0, p, sOff[(p >> 1) * S_TPB + tid]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
-    cv_in = inside_bits(cur);
     fill_coef(cur.n);
     __syncthreads();
 #pragma unroll
@@ -1211,7 +1204,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
         // the next stage's voxel s - 1 is requested in step s (1..8) and converted in step s + 1.  Step 0 of a brick's last stage
         // first replaces the offset table and the inside bits by the next brick's (~400 VALU: fillers here, 3k cycles at the
         // stage top before)
-        if (s == 0 && last_ch && more) { fill_offsets(nxt); if (!SPLIT) cv_next = inside_bits(nxt); }
+        if (s == 0 && last_ch && more) { cv_brick_next = fill_offsets(nxt); cv_next = cv_brick_next; }
         if constexpr (SPLIT) {
           // this step's share of the next stage's 16 pieces (step 0: after the offset table has been replaced)
           if (have_next) {
@@ -1290,92 +1283,92 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                           // every wave is done with the fragment images
     const int gz = z0 + wz + pl;
+    if (POOL) stamp();
     if constexpr (POOL) {
-      // lane = (channel quad c4, x-pair group j): row m's tile is read back as voxel PAIRS (2 j + 16 kk, + 1); rows 2 p, 2 p + 1
-      // are the y children of window row p; planes wz (even) and wz + 1 the z children.  Scan order of the reference (z, y, x;
-      // a later value wins only if strictly greater, or NaN): lower-index halves are combined first.
-      const int j = lane >> 3;
-      float4 pm[MR / 2][2];
-      unsigned pa[MR / 2][2];
+      // (x, y) pooling IN REGISTERS: a lane's accumulator registers (2 q, 2 q + 1) of row m are the two x children of pooled
+      // column X = (q & 1) + 4 (q >> 1) + 2 lh for ONE channel (column li of the tile), rows 2 p / 2 p + 1 of the same wave its
+      // y children: no LDS round trip per row (the row-tile version: 16 stores, a wait, 4 loads, a wait, eight times over --
+      // this single wave per SIMD is latency-bound there).  Planes wz (even) and wz + 1 hold the z children: odd planes publish
+      // through LDS.  Scan order of the reference (z, y, x; a later value wins only if strictly greater, or NaN): lower-index
+      // halves are combined first -- the same winners as kmh_maxpool3d_fwd.
       auto pick = [](float a, float b, unsigned ca, unsigned cb, float& m_, unsigned& c_) {
         const bool tb = (b > a) || (b != b);
         m_ = tb ? b : a; c_ = tb ? cb : ca;
       };
+      const int cl = co0 + li;
+      const float bch = (bias && cl < Cout) ? bias[cl] : 0.f;
+      float pvv[MR / 2][8];
+      unsigned pcc[MR / 2];                                                 // 8 window codes of 4 bits
 #pragma unroll
-      for (int m = 0; m < MR; ++m) {
-        float* tile = tile0 + (m & 1) * (32 * CH);
+      for (int p = 0; p < MR / 2; ++p) {
+        pcc[p] = 0u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * CH + li] = acc[m][0][r];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int xe = 2 * j + 16 * kk;
-          const float4 a = *reinterpret_cast<const float4*>(tile + xe * CH + col);
-          const float4 b = *reinterpret_cast<const float4*>(tile + (xe + 1) * CH + col);
-          float va[4] = {a.x * desc + bv.x, a.y * desc + bv.y, a.z * desc + bv.z, a.w * desc + bv.w};
-          float vb[4] = {b.x * desc + bv.x, b.y * desc + bv.y, b.z * desc + bv.z, b.w * desc + bv.w};
-          float mx[4];
-          unsigned cx[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (relu_out) { va[q] = fmaxf(va[q], 0.f); vb[q] = fmaxf(vb[q], 0.f); }
-            pick(va[q], vb[q], 0u, 1u, mx[q], cx[q]);                      // x children: codes 0 / 1
-          }
-          if ((m & 1) == 0) {
-            pm[m >> 1][kk] = float4{mx[0], mx[1], mx[2], mx[3]};
-            pa[m >> 1][kk] = cx[0] | (cx[1] << 8) | (cx[2] << 16) | (cx[3] << 24);
-          } else {                                                         // y children: + 2 for the second row
-            float4& P = pm[m >> 1][kk];
-            const unsigned A = pa[m >> 1][kk];
-            float o0, o1, o2, o3;
-            unsigned c0, c1, c2, c3;
-            pick(P.x, mx[0], A & 255u, cx[0] + 2u, o0, c0);
-            pick(P.y, mx[1], (A >> 8) & 255u, cx[1] + 2u, o1, c1);
-            pick(P.z, mx[2], (A >> 16) & 255u, cx[2] + 2u, o2, c2);
-            pick(P.w, mx[3], A >> 24, cx[3] + 2u, o3, c3);
-            P = float4{o0, o1, o2, o3};
-            pa[m >> 1][kk] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-          }
+        for (int q = 0; q < 8; ++q) {
+          float a0 = acc[2 * p][0][2 * q] * desc + bch, a1 = acc[2 * p][0][2 * q + 1] * desc + bch;
+          float b0 = acc[2 * p + 1][0][2 * q] * desc + bch, b1 = acc[2 * p + 1][0][2 * q + 1] * desc + bch;
+          if (relu_out) { a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f); b0 = fmaxf(b0, 0.f); b1 = fmaxf(b1, 0.f); }
+          float t0, t1, t;
+          unsigned c0, c1, c;
+          pick(a0, a1, 0u, 1u, t0, c0);                                      // x children of the first row: codes 0 / 1
+          pick(b0, b1, 0u, 1u, t1, c1);                                      // ... of the second row
+          pick(t0, t1, c0, c1 + 2u, t, c);                                   // y children: + 2 for the second row
+          pvv[p][q] = t;
+          pcc[p] |= c << (4 * q);
         }
       }
-      // z children: waves 1, 3 (odd planes) publish, waves 0, 2 combine and store
-      constexpr int XN = (MR / 2) * 2 * 64;                                // records per plane pair
-      float4* xv = reinterpret_cast<float4*>(sEp + 4 * (2 * 32 * CH) * 4);   // behind the 4 x 2 row tiles (32 KB)
-      unsigned* xa = reinterpret_cast<unsigned*>(xv + 2 * XN);
+      stamp();
+      // z children: waves 1, 3 (odd planes) publish, waves 0, 2 combine.  (Splitting the rest of the epilogue between the two
+      // waves of a pair -- each finishing two of the four window rows -- was measured: 4.08 against 3.95-4.08 ms, the selects
+      // that deal the halves cost what the idle partner would have saved.)
+      float* xv = reinterpret_cast<float*>(sEp);                              // [pair][36][64]: 32 values + 4 code words per lane
       const bool odd_plane = (wv & 1) != 0;
-      const int slot = (wv >> 1) * XN;
+      float* xs = xv + (wv >> 1) * (36 * 64) + lane;
       if (odd_plane) {
 #pragma unroll
-        for (int p = 0; p < MR / 2; ++p)
+        for (int p = 0; p < MR / 2; ++p) {
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) { xv[slot + (2 * p + kk) * 64 + lane] = pm[p][kk]; xa[slot + (2 * p + kk) * 64 + lane] = pa[p][kk]; }
+          for (int q = 0; q < 8; ++q) xs[(p * 8 + q) * 64] = pvv[p][q];
+          xs[(32 + p) * 64] = __uint_as_float(pcc[p]);
+        }
       }
       __syncthreads();
+      stamp();
       if (!odd_plane) {
-        const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1;
-        const int oz = (z0 + wz) >> 1;
+        // ... and transpose the pooled tile (4 rows x 16 columns x 32 channels) through this wave's 10 KB so that a lane stores 4
+        // channels of one pooled voxel (16 bytes; a wave instruction = 8 voxels = 1 KB of contiguous output)
+        float* tv = reinterpret_cast<float*>(sEp + 2 * 36 * 64 * 4) + (wv >> 1) * (64 * 32 + 64 * 8);      // [64 voxels][32]
+        unsigned char* tc = reinterpret_cast<unsigned char*>(tv + 64 * 32);                                 // [64 voxels][32] bytes
 #pragma unroll
         for (int p = 0; p < MR / 2; ++p) {
-          const int oy = (y0 + 2 * p) >> 1;
+          const unsigned B = __float_as_uint(xs[(32 + p) * 64]);
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            const int ox = (x0 >> 1) + j + 8 * kk;
-            const float4 Q = xv[slot + (2 * p + kk) * 64 + lane];
-            const unsigned B = xa[slot + (2 * p + kk) * 64 + lane];
-            const float4 P = pm[p][kk];
-            const unsigned A = pa[p][kk];
-            float o0, o1, o2, o3;
-            unsigned c0, c1, c2, c3;
-            pick(P.x, Q.x, A & 255u, (B & 255u) + 4u, o0, c0);
-            pick(P.y, Q.y, (A >> 8) & 255u, ((B >> 8) & 255u) + 4u, o1, c1);
-            pick(P.z, Q.z, (A >> 16) & 255u, ((B >> 16) & 255u) + 4u, o2, c2);
-            pick(P.w, Q.w, A >> 24, (B >> 24) + 4u, o3, c3);
-            if (oz < Do && oy < Ho && ox < Wo && co_ok) {
-              const long long e = ((((long long)n * Do + oz) * Ho + oy) * Wo + ox) * Cout + co;
-              *reinterpret_cast<float4*>(y + e) = float4{o0, o1, o2, o3};
-              pool_arg[e >> 2] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-              st1[0] += o0; st2[0] += o0 * o0; st1[1] += o1; st2[1] += o1 * o1;
-              st1[2] += o2; st2[2] += o2 * o2; st1[3] += o3; st2[3] += o3 * o3;
-            }
+          for (int q = 0; q < 8; ++q) {
+            const float Q = xs[(p * 8 + q) * 64];
+            float o;
+            unsigned c;
+            pick(pvv[p][q], Q, (pcc[p] >> (4 * q)) & 15u, ((B >> (4 * q)) & 15u) + 4u, o, c);
+            const int X = (q & 1) + 4 * (q >> 1) + 2 * lh;
+            tv[(p * 16 + X) * 32 + li] = o;
+            tc[(p * 16 + X) * 32 + li] = (unsigned char)c;
+          }
+        }
+        // (the wave's own LDS writes are ordered before its reads)
+        stamp();
+        const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1;
+        const int oz = (z0 + wz) >> 1;
+        const int jx = lane >> 3;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int vi = jx + 8 * k, pr = vi >> 4, X = vi & 15;
+          const float4 o4 = *reinterpret_cast<const float4*>(tv + vi * 32 + col);
+          const unsigned cw = *reinterpret_cast<const unsigned*>(tc + vi * 32 + col);
+          const int oy = (y0 >> 1) + pr, ox = (x0 >> 1) + X;
+          if (oz < Do && oy < Ho && ox < Wo && co_ok) {
+            const long long e = ((((long long)n * Do + oz) * Ho + oy) * Wo + ox) * Cout + co;
+            *reinterpret_cast<float4*>(y + e) = o4;
+            pool_arg[e >> 2] = cw;
+            st1[0] += o4.x; st2[0] += o4.x * o4.x; st1[1] += o4.y; st2[1] += o4.y * o4.y;
+            st1[2] += o4.z; st2[2] += o4.z * o4.z; st1[3] += o4.w; st2[3] += o4.w * o4.w;
           }
         }
       }
@@ -1413,6 +1406,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
       }
     }
     }   // !POOL
+    if (POOL) stamp();
     if (stats_partial) {
       double d1[4], d2[4];
 #pragma unroll
@@ -1421,6 +1415,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
 #pragma unroll
         for (int o = L4; o < 64; o <<= 1) { d1[j] += __shfl_xor(d1[j], o); d2[j] += __shfl_xor(d2[j], o); }
       }
+      if (POOL) stamp();
       __syncthreads();                                         // the tiles have been read back
       double* sred = reinterpret_cast<double*>(sEp);           // [wave][CH][2]
       if (lane < L4) {
@@ -1448,7 +1443,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     stamp();                                               // epilogue issued
     if (!more) break;
     cur = nxt;
-    if (!SPLIT) cv_in = inside_bits(cur);
+    cv_in = cv_brick_next;
     pb ^= 1;
   }
 }

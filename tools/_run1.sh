@@ -1,10 +1,6 @@
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
-: > gpurun_out/r5g_sweep.txt
-for r in 1 2; do
-for v in default 9_8 6_5 6_3 18_8 18_16; do
-  if [ $v = default ]; then L=""; else L="KEYMORPH_HIP_LIB=keymorph_amd/lib/ab/sp_$v.so"; fi
-  echo "== $v: $(env $L timeout 300 python tools/prof_split.py 256 2>&1 | grep "data gradient\|bit-identical" | tr '\n' ' ')" >> gpurun_out/r5g_sweep.txt
-done; done
-cat gpurun_out/r5g_sweep.txt
-bash tools/profile_round.sh r5g 2>&1 | tail -30
+timeout 1500 python -m pytest tests/test_conv_dispatch_gpu.py -x -q -k "pool" 2>&1 | tail -4 > gpurun_out/r5h_tests.txt
+for i in 1 2; do timeout 300 python tools/prof_pool.py 2>&1 | grep True >> gpurun_out/r5h_tests.txt; KEYMORPH_POOL_G=1 timeout 300 python tools/prof_pool.py 2>&1 | grep True >> gpurun_out/r5h_tests.txt; done
+KMH_G_TRACE=1 timeout 300 python tools/prof_pool.py 2>&1 | grep "POOL=1" | tail -1 | cut -c1-500 >> gpurun_out/r5h_tests.txt
+cat gpurun_out/r5h_tests.txt
