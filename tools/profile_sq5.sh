@@ -33,6 +33,7 @@ for shape in "128 64 64" "128 32 32" "256 16 32"; do
 done
 KEYMORPH_FWD_S=3 run_sq "KEYMORPH_FWD_S=3 python tools/prof_layer.py 256 16 32 f16x3 nomask (N = 2; the one-wave z-paired data gradient)" python tools/prof_layer.py 256 16 32 f16x3 nomask
 run_sq "python tools/prof_pool.py (16 -> 32 at 2 x 256^3 with the pooling epilogue, then without)" python tools/prof_pool.py
+run_sq "python tools/prof_split.py 256 (32 -> 16 data gradient at 2 x 256^3: blocked fp32 operand = conv3_fwd_g<1,ZP>, pre-split = conv3_fwd_s<1,ZP,SPLIT>)" python tools/prof_split.py 256
 for shape in "128 64 64" "128 32 32" "256 16 32"; do
   echo "== KMH_TIME=1 python tools/prof_layer.py $shape f16x3 nomask" >> $out
   KMH_TIME=1 python tools/prof_layer.py $shape f16x3 nomask >> $out 2>&1
@@ -48,4 +49,5 @@ for shape in "128 64 64" "128 32 32" "256 16 32"; do
 done
 KEYMORPH_FWD_S=3 KMH_G_TRACE=1 python tools/prof_layer.py 256 16 32 f16x3 nomask 2>&1 | grep KMH_G_TRACE | tail -3 >> $st
 KMH_G_TRACE=1 python tools/prof_pool.py 2>&1 | grep KMH_G_TRACE | head -3 >> $st
+KMH_G_TRACE=1 python tools/prof_split.py 256 2>&1 | grep "SPLIT=1" | tail -1 >> $st
 head -c 6000 $out
