@@ -109,9 +109,15 @@ RAGGED = [
     (1, (9, 243, 40), 24, 8),         # z-paired with Cout = 8
     (2, (7, 9, 31), 128, 72),         # 16 chunks, tiny volume: every brick partial
 ]
+# whole-brick volumes with several bricks per persistent workgroup (768 bricks for 256 workgroups): the launches on which the
+# 32-wide and z-paired tiles keep their output pieces in registers and store them under the next brick's first stage (round 5)
+WHOLE = [
+    (3, (32, 64, 128), 32, 32),
+    (2, (16, 32, 64), 16, 32),
+]
 
 
-@pytest.mark.parametrize("cfg", RAGGED)
+@pytest.mark.parametrize("cfg", RAGGED + WHOLE)
 def test_forward_kernel_g_ragged_vs_fp64_and_bit_identical(cfg, dispatch):
     """relu(conv3(x * scale + shift)) with output statistics, through the C ABI entry the backbone uses
     (kmh_conv3d_fwd_bf via backbone_ops.conv3_raw): conv3_fwd_g_kernel forced == conv3_fwd_bf_kernel bit for bit, and
@@ -150,7 +156,7 @@ def test_forward_kernel_g_ragged_vs_fp64_and_bit_identical(cfg, dispatch):
         B.set_conv_mode(old)
 
 
-@pytest.mark.parametrize("cfg", RAGGED)
+@pytest.mark.parametrize("cfg", RAGGED + WHOLE)
 @pytest.mark.parametrize("blocked", [False, True])
 def test_data_gradient_kernel_g_ragged_vs_fp64_and_bit_identical(cfg, blocked, dispatch):
     """the data gradient = the same kernel on tap-mirrored weights, no normalisation, no activation, premasked
@@ -592,7 +598,7 @@ def test_pool_backward_split_records_are_the_consumers_own_split(N, shape, C):
 
 
 @pytest.mark.parametrize("N,shape,Cin,Cout", [(2, (8, 16, 64), 32, 16), (1, (12, 20, 34), 32, 16), (3, (6, 10, 70), 16, 8),
-                                              (1, (4, 8, 32), 64, 16), (2, (44, 60, 100), 32, 16)])
+                                              (1, (4, 8, 32), 64, 16), (2, (44, 60, 100), 32, 16), (3, (32, 64, 128), 32, 16)])
 def test_presplit_data_gradient_is_bit_identical_to_the_fp32_operand(N, shape, Cin, Cout, dispatch):
     """The z-paired data gradient on the pre-split records (in_blocked = 2) against the same launch on the channel-blocked fp32
     scatter (in_blocked = 1: conv3_fwd_g_kernel<1,true>) and on the dense one (conv3_fwd_bf_kernel): identical bits, with the
