@@ -395,3 +395,27 @@ def test_bench_refuses_more_ranks_than_devices():
 def test_bench_rejects_world_size_mismatch():
     r, line = _bench(["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0", "KEYMORPH_BENCH_LAUNCH_CHECK": "1"})
     assert r.returncode != 0 and line is None and "WORLD_SIZE=4 but --gpus 2" in r.stderr
+
+
+def test_bench_rccl_transport_summary_and_sensor_fallback(tmp_path):
+    """bench.py's self-explaining pieces for the first multi-GPU run: the RCCL debug log of rank 0's communicator set-up is
+    folded into counts of its `via <transport>` channel lines (P2P/IPC = xGMI or PCIe peer access, SHM, NET/...), a missing
+    log says so, and the hwmon reader returns (None, None) instead of raising where there is no amdgpu device."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    log = tmp_path / "rccl.log"
+    log.write_text("h:1:1 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC\n"
+                   "h:1:1 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC\n"
+                   "h:1:1 [0] NCCL INFO Channel 00/0 : 7[7] -> 0[0] [receive] via NET/Socket/0\n"
+                   "h:1:1 [0] NCCL INFO Connected all rings\n"
+                   "h:1:1 [0] NCCL INFO comm 0x55 rank 0 nranks 8 cudaDev 0 busId c1000 - Init COMPLETE\n")
+    got = bench.rccl_transport_summary(str(log))
+    assert got["via"] == {"P2P/IPC": 2, "NET/Socket/0": 1}
+    assert any("Connected all rings" in ln for ln in got["lines"]) and any("nranks 8" in ln for ln in got["lines"])
+    assert "error" in bench.rccl_transport_summary(str(tmp_path / "absent.log"))
+    if not torch.cuda.is_available():
+        assert bench.gpu_sensors(0) == (None, None)
