@@ -913,6 +913,12 @@ static_assert(GPL <= S_PLANE && GTZ == 4 && GTY == S_MR, "wave = plane, 8 rows")
 #ifndef KMH_SP_BA
 #define KMH_SP_BA 9
 #endif
+#ifndef KMH_S_DEEP
+#define KMH_S_DEEP 1
+#endif
+#ifndef KMH_S_DEEP_RING_V      // 1 = the DEEP ring in "=v" registers: the variant that CRASHED (kept as the positive control of
+#define KMH_S_DEEP_RING_V 0    // tests/test_asm_audit_cpu.py; never built into the library)
+#endif
 #ifndef KMH_SP_PSTEPS
 #define KMH_SP_PSTEPS 5
 #endif
@@ -1030,7 +1036,15 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   // by the drain at the head of step j + 1, converted there).  (LDS-DMA pieces -- no staging registers -- cost this single wave 100+ cycles of issue
   // each, 16 per chunk: steps with two pieces ran 1.8k cycles against the 1.54k of their 48 MFMAs.)
   typedef float kmh_f4 __attribute__((ext_vector_type(4)));      // (a native vector: the asm's "=v" operand)
-  kmh_f4 rawq[2][2];
+  // DEEP (round 5, the 32-wide tile without a pre-split operand; KMH_S_DEEP=0: the A/B arm): its 24 MFMAs per step (768 cycles)
+  // do not cover an HBM round trip, and a `vmcnt(0)` at every step head made every raw load issued in step s a wait at step
+  // s + 1 (conversion steps 1200 cycles against 910 without a conversion).  As for SPLIT, the B ring holds a whole stage and
+  // fragments are requested 7 steps ahead, so only steps 0 and 7 drain; the raw voxels (compiler-visible loads: the compiler's
+  // own counted waits see only them, i.e. two asm B loads per step fewer than are in flight) are requested THREE steps before
+  // their conversion instead of one.
+  constexpr bool DEEP = (NT == 1) && !ZP && !SPLIT && (KMH_S_DEEP != 0);
+  constexpr int RQ = DEEP ? 4 : 2, CD = DEEP ? 3 : 1;      // raw ring slots; steps between a voxel's request and its conversion
+  kmh_f4 rawq[RQ][2];
   auto raw_issue = [&](int n, int ch, int slot, int off0, int off1) {
     const float* base = sample_base(n) + ch * chunk_stride;
     const float* p0 = base + off0;
@@ -1090,10 +1104,10 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   // s, so that the wave drains its memory queue only at the head of every BA-th step: the LDS-DMA pieces of the next stage's
   // halo, issued in the steps right after a drain, then have BA - SP_PS + 1 or more steps (thousands of cycles) to come in
   // from HBM before anything waits for them -- a drain at every step head would expose that latency 18 times per chunk.
-  constexpr int BD = SPLIT ? NST : KMH_S_BD;             // ring slots
-  constexpr int BA = SPLIT ? KMH_SP_BA : 1;              // request distance = drain period (steps)
+  constexpr int BD = (SPLIT || DEEP) ? NST : KMH_S_BD;   // ring slots
+  constexpr int BA = SPLIT ? KMH_SP_BA : (DEEP ? 7 : 1); // request distance = drain period (steps)
   constexpr int SP_PS = KMH_SP_PSTEPS;                   // SPLIT: the stage's 16 DMA pieces go out in steps 0 .. SP_PS - 1
-  static_assert(NST % BD == 0 && (SPLIT || BD == 2), "the ring slot of a step must not depend on the stage");
+  static_assert(NST % BD == 0 && (SPLIT || DEEP || BD == 2), "the ring slot of a step must not depend on the stage");
   static_assert(!SPLIT || (NST % BA == 0 && SP_PS < BA && NT == 1), "drains at steps 0, BA, ...; pieces land before the next one");
   auto piece_beg = [](int s) -> int { return s >= SP_PS ? S_NLD : (S_NLD * s) / SP_PS; };      // pieces of steps 0 .. SP_PS - 1
   constexpr int BL = 2 * NT;
@@ -1105,6 +1119,18 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   auto b_issue = [&](int slot) {
     const bf16x8* p0 = wp + o0;
     const bf16x8* p1 = p0 + term_stride;
+    // The stage-deep ring of the 32-wide tile lives in the ACCUMULATOR half of the register file.  With "=v" destinations the
+    // kernel needs 256 VGPRs + 218 AGPRs and the compiler, for which an asm load's destination is defined as soon as the
+    // statement ends, moved 11 of the ring's registers into AGPRs (v_accvgpr_write) while their loads were still in flight: the
+    // copies held stale data, the loads landed in registers since given to something else, the GPU faulted.  "=a" destinations
+    // leave it nothing to move (MFMA reads its B operand from AGPRs directly); tools/scan_asm_inflight.py audits the ISA of
+    // every instance for such copies and runs in the CPU test suite.
+    if constexpr (DEEP && !KMH_S_DEEP_RING_V) {
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bq[slot][0][0]) : "v"(p0) : "memory");
+      if (!AMP) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bq[slot][0][1]) : "v"(p1) : "memory");
+      o0 += step_stride;
+      return;
+    }
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[slot][0][0]) : "v"(p0) : "memory");
     if (!AMP) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[slot][0][1]) : "v"(p1) : "memory");
     if (NT == 2) {
@@ -1145,7 +1171,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   o0 = lh * CoutP + cur.cog * (32 * NT) + li;             // chunk 0 of the first brick: the fragments of steps 0 .. BA - 1
 #pragma unroll
   for (int d = 0; d < BA; ++d) b_issue(d);
-  if (SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (SPLIT || DEEP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int pb = 0;                                              // stage buffer holding the CURRENT stage's fragment images
   for (;;) {
     const bool more = next_item(vb, nxt);
@@ -1194,7 +1220,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
         // voxel s - 1, a previous brick's output stores
         // (SPLIT: only every BA-th step drains; step 0 of a brick's first stage does not either -- its fragments were waited
         // for ahead of the previous brick's epilogue, whose output stores thus stay in flight under BA steps of MFMAs)
-        if (!SPLIT || (s % BA == 0 && !(s == 0 && ch == 0))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(SPLIT || DEEP) || (s % BA == 0 && !(s == 0 && ch == 0))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (s + BA < NST) b_issue((s + BA) % BD);             // the fragments of step s + BA ...
         else if (have_next) {                                 // ... or of step s + BA - NST of the next stage
           if (s + BA == NST) o0 = (long long)nch * TERMS * term_stride + lh * CoutP + co0n + li;
@@ -1212,7 +1238,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
             for (int p = piece_beg(s); p < piece_beg(s + 1); ++p) dma_piece(nn, nch, pb ^ 1, p, sOff[(p >> 1) * S_TPB + tid]);
           }
         } else {
-        if (s >= 1 && s < 9 && have_next) raw_issue(nn, nch, (s - 1) % 2, dof0, dof1);
+        if (s >= 1 && s < 9 && have_next) raw_issue(nn, nch, (s - 1) % RQ, dof0, dof1);
         if (s < 8) { dof0 = sOff[s * S_TPB + tid]; dof1 = sOff[(8 + s) * S_TPB + tid]; }
         }
         if (KMH_S_ADB && s + 1 < NST) {
@@ -1230,7 +1256,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
             for (int q = 0; q < TERMS; ++q) a[0][m][q] = sIn[q * S_PLANE + ab + m * HX];
         }
         // the next stage's voxel s - 2 (requested in the last step)
-        if (!SPLIT && s >= 2 && s < 10) convert1(nch, cv_next, pb ^ 1, s - 2, rawq[(s - 2) % 2][0], rawq[(s - 2) % 2][1]);
+        if (!SPLIT && s >= 1 + CD && s < 9 + CD) convert1(nch, cv_next, pb ^ 1, s - 1 - CD, rawq[(s - 1 - CD) % RQ][0], rawq[(s - 1 - CD) % RQ][1]);
         // term-major over the 8 x NT accumulators: per accumulator the order of conv3_fwd_bf_kernel (smallest terms first)
 #pragma unroll
         for (int q3 = AMP ? 2 : 0; q3 < 3; ++q3)       // (AMP: hi x hi only)
@@ -1239,8 +1265,8 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
 #pragma unroll
             for (int t = 0; t < NT; ++t)
               acc[m][t] = mfma16<TERMS>(a[KMH_S_ADB ? (s & 1) : 0][m][q3 == 0 ? 1 : 0], bq[s % BD][t][q3 == 1 ? 1 : 0], acc[m][t]);
-        if ((SPLIT || !(s >= 2 && s < 10)) && KMH_S_RF) __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);      // plain steps: reads first too
-        if (!SPLIT && s >= 2 && s < 10) {
+        if ((SPLIT || !(s >= 1 + CD && s < 9 + CD)) && KMH_S_RF) __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);      // plain steps: reads first too
+        if (!SPLIT && s >= 1 + CD && s < 9 + CD) {
           // every LDS read of the block first (the next step's A fragments, the coefficients, the next offsets), then a few bare
           // MFMAs while they land -- a wait in the middle of the MFMA stream stalls it --, then the conversion's VALU a few per gap
           __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);
@@ -1264,7 +1290,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     // needed -- was measured: the 32-byte pieces those stores write cost 60-68k cycles per brick against 33k here.)
     // (SPLIT: the next stage's first fragments, requested in the last BA steps, land here -- L2 hits, long issued -- so that
     // step 0 of the next brick need not drain the queue the output stores below are about to fill)
-    if (SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (SPLIT || DEEP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int x0 = cur.bx * TX, y0 = cur.by * GTY, z0 = cur.bz * GTZ;
     constexpr int CH = 32 * NT;
     constexpr int L4 = CH / 4;
