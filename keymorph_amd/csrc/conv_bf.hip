@@ -916,6 +916,33 @@ static_assert(GPL <= S_PLANE && GTZ == 4 && GTY == S_MR, "wave = plane, 8 rows")
 #ifndef KMH_S_DEEP
 #define KMH_S_DEEP 1
 #endif
+#ifndef KMH_S_CW               // 1 = hand-counted waits in the kernels that convert their operand (0: full drains, the A/B arm)
+#define KMH_S_CW 1
+#endif
+#ifndef KMH_S_STAMPALL
+#define KMH_S_STAMPALL 0
+#endif
+#ifndef KMH_S_IL               // 1 = LDS reads / conversion VALU dealt over the MFMA gaps of the whole step (0: reads first, the A/B arm)
+#define KMH_S_IL 1
+#endif
+#ifndef KMH_S_ILR              // gaps that take LDS reads, reads per such gap
+#define KMH_S_ILR 12
+#endif
+#ifndef KMH_S_ILRN
+#define KMH_S_ILRN 2
+#endif
+#ifndef KMH_S_ILV0             // first gap that takes conversion VALU; VALU per gap on the 32-wide / 64-wide tile
+#define KMH_S_ILV0 3
+#endif
+#ifndef KMH_S_ILV1
+#define KMH_S_ILV1 3
+#endif
+#ifndef KMH_S_ILV2
+#define KMH_S_ILV2 2
+#endif
+#ifndef KMH_S_UNCOND           // 1 = the step loop requests the "next stage's" fragments / voxels / pieces even when there is no next
+#define KMH_S_UNCOND 1         // stage (addresses stay valid: stage 0 of the current pair): no branch inside a step, one scheduling
+#endif                         // region per step (0 = the A/B arm)
 #ifndef KMH_S_DEEP_RING_V      // 1 = the DEEP ring in "=v" registers: the variant that CRASHED (kept as the positive control of
 #define KMH_S_DEEP_RING_V 0    // tests/test_asm_audit_cpu.py; never built into the library)
 #endif
@@ -1043,17 +1070,52 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   // own counted waits see only them, i.e. two asm B loads per step fewer than are in flight) are requested THREE steps before
   // their conversion instead of one.
   constexpr bool DEEP = (NT == 1) && !ZP && !SPLIT && (KMH_S_DEEP != 0);
-  constexpr int RQ = DEEP ? 4 : 2, CD = DEEP ? 3 : 1;      // raw ring slots; steps between a voxel's request and its conversion
+  // CW (round 5, every kernel that converts its operand): COUNTED waits.  Loads return in issue order, so `vmcnt(K)` with K =
+  // the number of loads issued after the one a step needs says exactly "that one has landed" -- and leaves the younger ones in
+  // flight: a raw voxel requested CD steps before its conversion gets CD steps of MFMAs to come in from HBM (a full drain at the
+  // next step head gave it one: 1.7-1.9k cycles against 0.9k idle and 2-4k loaded HBM latency; the conversion steps of the
+  // 64-wide tile ran 2.1-2.6k cycles against 1.93k for plain ones).  The raw loads are inline asm as the fragment loads are
+  // (the compiler's own waits for visible loads do not count the asm ones, i.e. wait for too much), every wait is followed by
+  // empty asm statements that re-define the registers it covers (so no use can move above it), and tools/scan_asm_inflight.py
+  // checks in the ISA that no destination is copied or spilled between its load and the wait that covers it -- the root of
+  // round 4's "counted waits give run-to-run different results".  Output stores of an epilogue are OLDER than every load that
+  // is waited for with a count (the fragments requested before an epilogue are drained / waited for with vmcnt(0)), so their
+  // completion order does not matter: pending stores only make a counted wait stricter.
+  constexpr bool CW = !SPLIT && (KMH_S_CW != 0);
+  static_assert(!CW || KMH_S_UNCOND, "counted waits need the same loads in every stage");
+  constexpr int CD = DEEP ? 3 : (CW ? 2 : 1);              // steps between a voxel's request and its conversion
+  constexpr int RQ = CD + 1;                               // raw ring slots
   kmh_f4 rawq[RQ][2];
   auto raw_issue = [&](int n, int ch, int slot, int off0, int off1) {
     const float* base = sample_base(n) + ch * chunk_stride;
     const float* p0 = base + off0;
     const float* p1 = base + off1;
-    // (compiler-visible loads, not inline asm: a destination register of an asm load is "defined" for the compiler the moment
-    // the statement ends, so under register pressure it may copy or spill it before the data has arrived -- seen as
-    // intermittent wrong results; its own waits for these loads are merely stricter than the counted ones of the B ring)
-    rawq[slot][0] = *reinterpret_cast<const kmh_f4*>(p0);
-    rawq[slot][1] = *reinterpret_cast<const kmh_f4*>(p1);
+    if constexpr (CW) {
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rawq[slot][0]) : "v"(p0) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rawq[slot][1]) : "v"(p1) : "memory");
+    } else {
+      // (compiler-visible loads: its own waits for them are merely stricter than needed)
+      rawq[slot][0] = *reinterpret_cast<const kmh_f4*>(p0);
+      rawq[slot][1] = *reinterpret_cast<const kmh_f4*>(p1);
+    }
+  };
+  auto raw_tie = [&](int slot) {                           // (after a wait: the slot's registers are defined HERE)
+    asm volatile("" : "+v"(rawq[slot][0]));
+    asm volatile("" : "+v"(rawq[slot][1]));
+  };
+  auto vm_wait = [](int K) {                               // s_waitcnt vmcnt(K), K a constant after unrolling
+    switch (K) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
   };
   int coef_n = -1;
   auto fill_coef = [&](int n_) {                      // (the caller's barrier publishes it)
@@ -1139,6 +1201,25 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     }
     o0 += step_stride;
   };
+  auto b_tie = [&](int slot) {                           // (after a wait: the slot's registers are defined HERE)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = AMP ? 0 : 1; q >= 0; --q) {
+        if constexpr (DEEP && !KMH_S_DEEP_RING_V) asm volatile("" : "+a"(bq[slot][t][q]));
+        else asm volatile("" : "+v"(bq[slot][t][q]));
+      }
+  };
+  // CW: loads issued after the youngest one step s needs, up to the wait at its head (a step issues its fragments, then, in
+  // steps 1 .. 8, a raw voxel's two halves): the fragments of step s were requested BA steps earlier, the voxel it converts CD
+  constexpr int NBL = NT * (AMP ? 1 : 2);                // loads of one b_issue
+  auto cw_count = [&](int s_) -> int {
+    auto nr = [&](int t) -> int { t = ((t % NST) + NST) % NST; return (t >= 1 && t < 9) ? 2 : 0; };
+    int yr = 0, yb = nr(s_ - BA);
+    for (int t = s_ - CD + 1; t < s_; ++t) yr += NBL + nr(t);
+    for (int t = s_ - BA + 1; t < s_; ++t) yb += NBL + nr(t);
+    return yr < yb ? yr : yb;
+  };
   auto a_offset = [&](int s) -> int {                    // LDS slot offset of this lane's A fragment of step s, row 0
     constexpr int last_tap = ZP ? 35 : 26;
     const int tapA = 2 * s, tapB = (2 * s + 1 > last_tap) ? last_tap : 2 * s + 1;      // padded half-step: zero weights
@@ -1165,6 +1246,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     for (int i = 0; i < S_NCV; ++i) {
       raw_issue(cur.n, 0, 0, sOff[i * S_TPB + tid], sOff[(8 + i) * S_TPB + tid]);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (CW) raw_tie(0);
       convert1(0, cv_in, 0, i, rawq[0][0], rawq[0][1]);
     }
   }
@@ -1195,7 +1277,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
       stamp();                                             // barrier passed
       const bf16x8* sIn = reinterpret_cast<const bf16x8*>(gsm + pb * S_BUF_BYTES);      // [TERMS][S_PLANE]
       const bool last_ch = ch + 1 == nchunk;
-      const bool have_next = !last_ch || more;
+      const bool have_next = KMH_S_UNCOND || !last_ch || more;
       const int nn = (last_ch && more) ? nxt.n : n, nch = last_ch ? 0 : ch + 1;      // (no next stage: any valid pair)
       unsigned cv_next = last_ch ? 0u : cv_in;             // (the next BRICK's table and bits: inside step 0, below)
       if (!SPLIT && nn != coef_n) {                        // uniform, rare: the work list moves on to another sample
@@ -1220,12 +1302,19 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
         // voxel s - 1, a previous brick's output stores
         // (SPLIT: only every BA-th step drains; step 0 of a brick's first stage does not either -- its fragments were waited
         // for ahead of the previous brick's epilogue, whose output stores thus stay in flight under BA steps of MFMAs)
-        if (!(SPLIT || DEEP) || (s % BA == 0 && !(s == 0 && ch == 0))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (CW: counted -- the fragments of this step and the voxel it converts have landed, younger requests stay in flight;
+        // DEEP: the first steps of a brick's first stage need nothing that was not waited for ahead of the previous epilogue)
+        if constexpr (CW) {
+          if (!(DEEP && ch == 0 && s <= CD)) vm_wait(cw_count(s));
+          b_tie(s % BD);
+          if (s >= 1 + CD && s < 9 + CD) raw_tie((s - 1 - CD) % RQ);
+        } else if (!(SPLIT || DEEP) || (s % BA == 0 && !(s == 0 && ch == 0))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (s + BA < NST) b_issue((s + BA) % BD);             // the fragments of step s + BA ...
         else if (have_next) {                                 // ... or of step s + BA - NST of the next stage
           if (s + BA == NST) o0 = (long long)nch * TERMS * term_stride + lh * CoutP + co0n + li;
           b_issue((s + BA - NST) % BD);
         }
+        if (CW && s >= 1 && s < 9) raw_issue(nn, nch, (s - 1) % RQ, dof0, dof1);      // (CW: a fixed place in the load order)
         __builtin_amdgcn_sched_barrier(0);
         // the next stage's voxel s - 1 is requested in step s (1..8) and converted in step s + 1.  Step 0 of a brick's last stage
         // first replaces the offset table and the inside bits by the next brick's (~400 VALU: fillers here, 3k cycles at the
@@ -1238,7 +1327,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
             for (int p = piece_beg(s); p < piece_beg(s + 1); ++p) dma_piece(nn, nch, pb ^ 1, p, sOff[(p >> 1) * S_TPB + tid]);
           }
         } else {
-        if (s >= 1 && s < 9 && have_next) raw_issue(nn, nch, (s - 1) % RQ, dof0, dof1);
+        if (!CW && s >= 1 && s < 9 && have_next) raw_issue(nn, nch, (s - 1) % RQ, dof0, dof1);
         if (s < 8) { dof0 = sOff[s * S_TPB + tid]; dof1 = sOff[(8 + s) * S_TPB + tid]; }
         }
         if (KMH_S_ADB && s + 1 < NST) {
@@ -1265,6 +1354,20 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
 #pragma unroll
             for (int t = 0; t < NT; ++t)
               acc[m][t] = mfma16<TERMS>(a[KMH_S_ADB ? (s & 1) : 0][m][q3 == 0 ? 1 : 0], bq[s % BD][t][q3 == 1 ? 1 : 0], acc[m][t]);
+        constexpr int NMF = MR * NT * (AMP ? 1 : 3);          // MFMAs of a step
+        if constexpr (KMH_S_IL != 0) {
+          // ONE scheduling region per step (no branch inside: KMH_S_UNCOND), its single-issue instructions dealt over the MFMA
+          // gaps: a wave alone on its SIMD hides about five of them beside a 32-cycle MFMA, and whatever sits in front of the
+          // step's first MFMA runs with the matrix pipe idle (the "reads first" arrangement put 30-60 instructions there).
+          const bool conv_step = !SPLIT && s >= 1 + CD && s < 9 + CD;
+#pragma unroll
+          for (int k = 0; k < NMF; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // one MFMA
+            if (k < KMH_S_ILR) __builtin_amdgcn_sched_group_barrier(0x100, KMH_S_ILRN, 0);      // LDS reads: early gaps
+            if (k == 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                       // the raw voxel's two loads
+            if (conv_step && k >= KMH_S_ILV0) __builtin_amdgcn_sched_group_barrier(0x002, NT == 2 ? KMH_S_ILV2 : KMH_S_ILV1, 0);
+          }
+        } else {
         if ((SPLIT || !(s >= 1 + CD && s < 9 + CD)) && KMH_S_RF) __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);      // plain steps: reads first too
         if (!SPLIT && s >= 1 + CD && s < 9 + CD) {
           // every LDS read of the block first (the next step's A fragments, the coefficients, the next offsets), then a few bare
@@ -1277,9 +1380,10 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // ... one MFMA
           }
         }
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (s == 0 || s == 9 || s == NST - 1) stamp();      // steps 0 / .. 9 / .. NST - 1 done
+        if (KMH_S_STAMPALL || s == 0 || s == 9 || s == NST - 1) stamp();      // steps 0 / .. 9 / .. NST - 1 done (debug builds: every step)
       }
       if (!last_ch) pb ^= 1;                               // (after a brick's last stage the epilogue still uses its buffer)
     }
