@@ -264,6 +264,17 @@ size_t kmh_up2_wgrad_gemm_ws_bytes(int N, int V, int Cl, int J);
 int kmh_up2_wgrad_gemm(const float* A, const float* B, float* C, int N, int V, int Cl, int J, int terms,
                        const float* ascale, const float* bscale, const float* a_scale, const float* a_shift, void* ws,
                        void* stream);
+/* Round 5: the two calls above in ONE product, the box sums formed on the fly from dz (never stored): C (N, Cl, 27 Cout) for
+ * xl (N, Dl, Hl, Wl, Cl) the RAW low tensor (a_scale / a_shift (N, Cl): GroupNorm's affine, or both NULL), dz (N, 2Dl, 2Hl,
+ * 2Wl, Cout) or channel-blocked (dz_blocked != 0), ascale / dscale = {S, 1/S} range scales of the normalised low tensor and
+ * of dz (the box sums are scaled by S / 8).  fp16 split only (terms == 2), Cl % 4 == 0, Cout % 8 == 0: kmh_up2_wgrad_fold_ok.
+ * Replaces autograd's weight gradient of interpolate(nearest x2) + cat + conv3d for the upsampled channels
+ * (keymorph/unet3d/buildingblocks.py:471-475, :46-78). */
+int kmh_up2_wgrad_fold_ok(int Cl, int Cout, int terms);
+size_t kmh_up2_wgrad_fold_ws_bytes(int N, int Dl, int Hl, int Wl, int Cl, int Cout);
+int kmh_up2_wgrad_fold(const float* xl, const float* dz, float* C, int N, int Dl, int Hl, int Wl, int Cl, int Cout,
+                       const float* ascale, const float* dscale, const float* a_scale, const float* a_shift, int dz_blocked,
+                       void* ws, void* stream);
 int kmh_conv3d_up2_fwd(const float* xl, const float* scale, const float* shift, int Ctot, int cofs, const void* packed,
                        float* y, int N, int Dl, int Hl, int Wl, int Cl, int Cout, int terms, const float* ascale,
                        const float* wscale, void* stream);

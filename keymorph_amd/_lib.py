@@ -79,6 +79,9 @@ PROTOS = {
     "kmh_up2_boxsum": (_i, [_f, _f, _i, _i, _i, _i, _i, _i, _f]),
     "kmh_up2_wgrad_gemm_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "kmh_up2_wgrad_gemm": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
+    "kmh_up2_wgrad_fold_ok": (_i, [_i, _i, _i]),
+    "kmh_up2_wgrad_fold_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "kmh_up2_wgrad_fold": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f]),
     "kmh_conv3d_up2_pack_bytes": (_sz, [_i, _i, _i]),
     "kmh_conv3d_up2_pack_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f]),
     "kmh_conv3d_up2_fwd": (_i, [_f, _f, _f, _i, _i, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),

@@ -372,6 +372,17 @@ BLOCKED_STATS = {"handoffs": 0}      # channel-blocked gradient hand-offs perfor
 SPLIT_STATS = {"handoffs": 0}        # pooled gradients scattered straight into pre-split fp16 records (tests)
 
 
+UP2_STATS = {"fold": 0, "boxsum": 0}      # which weight-gradient route the fused upsample + concat convolution took (tests)
+
+
+def up2_wgrad_fold_ok(Cl, Cout, terms):
+    """The upsampled channels' weight gradient with the box sums formed inside the product (kmh_up2_wgrad_fold);
+    KEYMORPH_NO_UP2_FOLD=1: the box-sum tensor + matrix product route (the A/B arm)."""
+    if os.environ.get("KEYMORPH_NO_UP2_FOLD"):
+        return False
+    return bool(_lib.load().kmh_up2_wgrad_fold_ok(int(Cl), int(Cout), int(terms)))
+
+
 def pool_grad_split_ok(N, D, H, W, Cin, Cout) -> bool:
     """May the backward of a (Cin -> Cout) conv + pooling operator scatter the pooled gradient straight into the pre-split
     records (`kmh_maxpool3d_bwd_split`)?  Both consumers must take them: the data gradient (Cout -> Cin, the z-paired tile of
@@ -671,20 +682,28 @@ class _UpCatConvGCR(torch.autograd.Function):
                            xscale=ctx.ascale, dscale=dscale, dz_blocked=blk, fold=(weight[:, :Cs].contiguous(), bhat_s))
         if Cout % 4 == 0 and not os.environ.get("KEYMORPH_NO_UPCONV_WGRAD"):
             Vl = V // 8
-            boxes = _f32((N, Vl, 27 * Cout), dy.device)
-            check(lib.kmh_up2_boxsum(_p(dy), _p(boxes), N, D // 2, H // 2, W // 2, Cout, int(blk), _stream()), "kmh_up2_boxsum")
             sc_l, sh_l = scale[:, Cs:].contiguous(), shift[:, Cs:].contiguous()   # named: they must outlive the launch
             terms = _TERMS[CONV_MODE]
             dwn = _f32((N, Cl, 27, Cout), dy.device)
-            gws = workspace(int(lib.kmh_up2_wgrad_gemm_ws_bytes(N, Vl, Cl, 27 * Cout)), dy.device, "wgrad")
-            bsc = (dscale * _const(dy.device, 0.125, 8.0)) if terms == 2 else None   # sums of 8
             if _lib.profiler.enabled:
                 _lib.profiler.meta = {"flops": 2.0 * 27 * Cl * Cout * N * Vl, "shape": (N, Vl, Cl, 27 * Cout)}
-            # (the raw low tensor: GroupNorm's affine is applied while the product stages it)
-            check(lib.kmh_up2_wgrad_gemm(_p(low), _p(boxes), _p(dwn), N, Vl, Cl, 27 * Cout, terms,
-                                         _p(ctx.ascale if terms == 2 else None), _p(bsc), _p(sc_l), _p(sh_l), _p(gws),
-                                         _stream()), "kmh_up2_wgrad_gemm")
-            del boxes
+            if up2_wgrad_fold_ok(Cl, Cout, terms):
+                # round 5: the box sums are formed inside the product (from LDS), never stored
+                UP2_STATS["fold"] += 1
+                gws = workspace(int(lib.kmh_up2_wgrad_fold_ws_bytes(N, D // 2, H // 2, W // 2, Cl, Cout)), dy.device, "wgrad")
+                check(lib.kmh_up2_wgrad_fold(_p(low), _p(dy), _p(dwn), N, D // 2, H // 2, W // 2, Cl, Cout, _p(ctx.ascale),
+                                             _p(dscale), _p(sc_l), _p(sh_l), int(blk), _p(gws), _stream()), "kmh_up2_wgrad_fold")
+            else:
+                UP2_STATS["boxsum"] += 1
+                boxes = _f32((N, Vl, 27 * Cout), dy.device)
+                check(lib.kmh_up2_boxsum(_p(dy), _p(boxes), N, D // 2, H // 2, W // 2, Cout, int(blk), _stream()), "kmh_up2_boxsum")
+                gws = workspace(int(lib.kmh_up2_wgrad_gemm_ws_bytes(N, Vl, Cl, 27 * Cout)), dy.device, "wgrad")
+                bsc = (dscale * _const(dy.device, 0.125, 8.0)) if terms == 2 else None   # sums of 8
+                # (the raw low tensor: GroupNorm's affine is applied while the product stages it)
+                check(lib.kmh_up2_wgrad_gemm(_p(low), _p(boxes), _p(dwn), N, Vl, Cl, 27 * Cout, terms,
+                                             _p(ctx.ascale if terms == 2 else None), _p(bsc), _p(sc_l), _p(sh_l), _p(gws),
+                                             _stream()), "kmh_up2_wgrad_gemm")
+                del boxes
             dw_l = dwn.sum(0).permute(2, 0, 1).reshape(Cout, Cl, 3, 3, 3)
             wl = weight[:, Cs:].reshape(Cout, Cl, 27).permute(1, 2, 0)                         # (Cl, 27, Cout)
             bhat_l = (dwn.double() * wl.double().unsqueeze(0)).sum(dim=(2, 3))

@@ -2159,6 +2159,218 @@ __global__ __launch_bounds__(256) void up2_wgrad_reduce_kernel(const float* __re
   }
 }
 
+
+// ---- round 5: the same product with the box sums formed ON THE FLY (the 27 box-sum tensors -- 4.5 GB written by up2_boxsum and
+// read back by the product above, which ran at the HBM rate of that -- never exist).  Reference: autograd of the decoder's
+// interpolate(nearest x2) + cat + SingleConv (keymorph/unet3d/buildingblocks.py:471-475, :46-78).
+// One K step = a 4 x 4 x 2 tile of low voxels (32).  Workgroup = 128 rows of Cl x (27 taps x 8 couts = 216 columns, 7 MFMA
+// tiles) over a slab of K tiles; wave = one 32-row tile x all 7 column tiles (112 accumulators).  Per step: the tile's
+// 10 x 10 x 6 window of dz (8 channels: 19 KB, prefetched during the previous step's MFMAs) goes to LDS as fp32, 192 threads form
+// the 32 x 27 x 8 box sums from it with the additions of up2_boxsum_tiled_kernel in the same order (bit-identical sums), scale
+// them by S_dz / 8, split them and write the B image; the A image (raw low tensor with GroupNorm's affine) as in the kernel above.
+// Two workgroups per CU (76.5 KB of LDS each): one's box sums (VALU) run beside the other's MFMAs.
+// Measured (profiles/r5r_up2_wgrad_fold.txt, N = 4, dz channel-blocked): 128 -> 64 at 128^3: 5.12 -> 2.95 ms, 256 -> 128 at 64^3:
+// 1.91 -> 1.40 ms.  With the box sums AND the MFMAs compiled out a launch still takes 2.08 / 1.03 ms: the kernel is bound by what
+// a CU can load (window 19.2 KB + A rows 16 KB per step: 9.2 GB per launch, mostly L2 hits, at ~ 10 B / cycle / CU); the box sums
+// add 0.5 ms, the MFMAs 0.25.  Fetching the window before or after the box sums: no difference.
+#ifndef WF_EARLY_W
+#define WF_EARLY_W 1
+#endif
+constexpr int WF_HX = 10, WF_HY = 10, WF_HZ = 6, WF_VOX = WF_HX * WF_HY * WF_HZ;      // window of a 4 x 4 x 2 low tile
+constexpr int WF_NC = 224;                                                           // 216 columns, padded to 7 x 32
+constexpr int WF_LDS = WF_VOX * 2 * 16 + 2 * 128 * GPITCH + 2 * WF_NC * GPITCH + 1024;      // 19200 + 20480 + 35840 + 1024
+template <bool AMP>
+__global__ __launch_bounds__(256, 2) void up2_wgrad_fold_kernel(
+    const float* __restrict__ xl, const float* __restrict__ dz, float* __restrict__ Cp, int Dl, int Hl, int Wl, int Cl, int Cout,
+    int tiles_x, int tiles_y, int ktiles, int tiles_per_slab, int ntm, int nto, const float* __restrict__ ascale,
+    const float* __restrict__ dscale, const float* __restrict__ a_scale, const float* __restrict__ a_shift, int dz_blocked,
+    int xcd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wf_lds[];
+  float4* sW = reinterpret_cast<float4*>(wf_lds);                                   // [voxel][2 quads]
+  unsigned char* sA = wf_lds + WF_VOX * 2 * 16;                                     // [2 terms][128 rows][GPITCH]
+  unsigned char* sB = sA + 2 * 128 * GPITCH;                                        // [2 terms][224 rows][GPITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int n = blockIdx.z;
+  int item = xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int tn = item % nto; item /= nto;                 // the cout octet (the octets of one K slab read the same rows of xl)
+  const int tm = item % ntm;
+  const int slab = item / ntm;
+  const int m0 = tm * 128;
+  const int D = 2 * Dl, H = 2 * Hl, W = 2 * Wl;
+  const long long Vl = (long long)Dl * Hl * Wl, Vh = (long long)D * H * W;
+  const float sa = ascale[0], sb = dscale[0] * 0.125f;                             // box sums: |sum of 8| <= 8 max|dz|
+  const float desc = ascale[1] * dscale[1] * 8.f;
+  const float* xn = xl + (long long)n * Vl * Cl;
+  const float* dn = dz + (long long)n * Vh * Cout;
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  for (int e = tid; e < 2 * 8 * GPITCH / 4; e += 256) {                             // columns 216 .. 223 stay zero
+    const int t = e / (8 * GPITCH / 4), w = e % (8 * GPITCH / 4);
+    reinterpret_cast<unsigned*>(sB + t * WF_NC * GPITCH + 216 * GPITCH)[w] = 0u;
+  }
+  const int t_beg = slab * tiles_per_slab;
+  int t_end = t_beg + tiles_per_slab;
+  if (t_end > ktiles) t_end = ktiles;
+  // staging registers: the window (600 voxels x 2 quads = 1200 float4: 5 per thread), the A rows (16 voxel pairs x 32 quads)
+  float4 pw[5], pa[2][2];
+  int x0 = 0, y0 = 0, z0 = 0;                                                       // the tile the registers hold
+  auto fetch_w = [&](int t) {                             // the window of tile t
+    const int bx = t % tiles_x, by = (t / tiles_x) % tiles_y, bz = t / (tiles_x * tiles_y);
+    const int wx = 8 * bx - 1, wy = 8 * by - 1, wz = 4 * bz - 1;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = tid + i * 256, q = e & 1, v = e >> 1;
+      const int lx = v % WF_HX, ly = (v / WF_HX) % WF_HY, lz = v / (WF_HX * WF_HY);
+      const int ux = wx + lx, uy = wy + ly, uz = wz + lz;
+      pw[i] = z4;
+      if (e < 2 * WF_VOX && (unsigned)ux < (unsigned)W && (unsigned)uy < (unsigned)H && (unsigned)uz < (unsigned)D) {
+        const long long vox = ((long long)uz * H + uy) * W + ux;
+        const float* src = dz_blocked ? dn + ((long long)tn * Vh + vox) * 8 + 4 * q : dn + vox * Cout + 8 * tn + 4 * q;
+        pw[i] = *reinterpret_cast<const float4*>(src);
+      }
+    }
+  };
+  auto fetch_a = [&](int t) {                             // the A rows of tile t (which becomes the tile the registers hold)
+    const int bx = t % tiles_x, by = (t / tiles_x) % tiles_y, bz = t / (tiles_x * tiles_y);
+    x0 = 4 * bx; y0 = 4 * by; z0 = 2 * bz;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * 256, cq = (e & 7) + 8 * (e >> 7), kp = (e >> 3) & 15;      // 8 lanes: one 128-byte line of a voxel row
+      const int k = 2 * kp, gx = x0 + (k & 3), gy = y0 + ((k >> 2) & 3), gz = z0 + (k >> 4), ca = m0 + 4 * cq;
+      const bool rowok = gy < Hl && gz < Dl && ca < Cl;
+      const float* src = xn + (((long long)gz * Hl + gy) * Wl + gx) * Cl + ca;
+      pa[i][0] = (rowok && gx < Wl) ? *reinterpret_cast<const float4*>(src) : z4;
+      pa[i][1] = (rowok && gx + 1 < Wl) ? *reinterpret_cast<const float4*>(src + Cl) : z4;
+    }
+  };
+  float* sC = reinterpret_cast<float*>(sB + 2 * WF_NC * GPITCH);                     // GroupNorm's affine of the A rows: [2][128]
+  if (tid < 128) {
+    const int ca = m0 + tid;
+    sC[tid] = (a_scale && ca < Cl) ? a_scale[(long long)n * Cl + ca] : 1.f;
+    sC[128 + tid] = (a_scale && ca < Cl) ? a_shift[(long long)n * Cl + ca] : 0.f;
+  }
+  auto commit = [&]() {                                   // registers -> the window and the A image (tile x0, y0, z0)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = tid + i * 256;
+      if (e < 2 * WF_VOX) sW[e] = pw[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * 256, cq = (e & 7) + 8 * (e >> 7), kp = (e >> 3) & 15;
+      const int k = 2 * kp, gx = x0 + (k & 3), gy = y0 + ((k >> 2) & 3), gz = z0 + (k >> 4);
+      const bool rowok = gy < Hl && gz < Dl;
+      const bool v0 = rowok && gx < Wl, v1 = rowok && gx + 1 < Wl;              // voxels past the volume: zero rows (no shift)
+      const float4 sc = *reinterpret_cast<const float4*>(sC + 4 * cq), sh = *reinterpret_cast<const float4*>(sC + 128 + 4 * cq);
+      const float a0[4] = {v0 ? fmaf(pa[i][0].x, sc.x, sh.x) : 0.f, v0 ? fmaf(pa[i][0].y, sc.y, sh.y) : 0.f,
+                           v0 ? fmaf(pa[i][0].z, sc.z, sh.z) : 0.f, v0 ? fmaf(pa[i][0].w, sc.w, sh.w) : 0.f};
+      const float a1[4] = {v1 ? fmaf(pa[i][1].x, sc.x, sh.x) : 0.f, v1 ? fmaf(pa[i][1].y, sc.y, sh.y) : 0.f,
+                           v1 ? fmaf(pa[i][1].z, sc.z, sh.z) : 0.f, v1 ? fmaf(pa[i][1].w, sc.w, sh.w) : 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned w[2];
+        split_pair<2>(a0[j] * sa, a1[j] * sa, w);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<unsigned*>(sA + t * 128 * GPITCH + (4 * cq + j) * GPITCH + 4 * kp) = w[t];
+      }
+    }
+  };
+  auto boxes = [&]() {                                    // window -> the B image: thread = (low voxel m, kz, channel quad q)
+    if (tid >= 192) return;
+    const int q = tid & 1, kz = (tid >> 1) % 3, m = tid / 6;
+    const int lmx = m & 3, lmy = (m >> 2) & 3, lmz = m >> 4;
+    float4 Y[3][3];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) (&Y[0][0])[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // window index i = u - (2m - 1) in 0..3 per axis; tap k (offset k - 1) sums i in {2 - k, 3 - k}
+#pragma unroll
+    for (int dzp = 0; dzp < 2; ++dzp) {
+      const int lz = 2 * lmz + (2 - kz) + dzp;
+#pragma unroll
+      for (int iy = 0; iy < 4; ++iy) {
+        const float4* row = sW + (((lz * WF_HY + 2 * lmy + iy) * WF_HX + 2 * lmx) * 2 + q);
+        const float4 a4[4] = {row[0], row[2], row[4], row[6]};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float4 u = a4[2 - kx], v = a4[3 - kx];
+          const float4 xs = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+            if (iy == 2 - ky || iy == 3 - ky) {
+              Y[ky][kx].x += xs.x; Y[ky][kx].y += xs.y; Y[ky][kx].z += xs.z; Y[ky][kx].w += xs.w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);     // (one window row at a time: 32 rows hoisted together spill the accumulators)
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+      const float4 y = (&Y[0][0])[a];
+      const int col = (kz * 9 + a) * 8 + 4 * q;            // column = tap x 8 + cout within the octet
+      unsigned w01[2], w23[2];
+      split_pair<2>(y.x * sb, y.y * sb, w01);
+      split_pair<2>(y.z * sb, y.w * sb, w23);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        unsigned char* base = sB + t * WF_NC * GPITCH + col * GPITCH + 2 * m;
+        *reinterpret_cast<unsigned short*>(base) = (unsigned short)(w01[t] & 0xffffu);
+        *reinterpret_cast<unsigned short*>(base + GPITCH) = (unsigned short)(w01[t] >> 16);
+        *reinterpret_cast<unsigned short*>(base + 2 * GPITCH) = (unsigned short)(w23[t] & 0xffffu);
+        *reinterpret_cast<unsigned short*>(base + 3 * GPITCH) = (unsigned short)(w23[t] >> 16);
+      }
+    }
+  };
+  if (t_beg < t_end) { fetch_w(t_beg); fetch_a(t_beg); }
+  for (int t = t_beg; t < t_end; ++t) {
+    __syncthreads();                           // the previous step's fragment reads are done
+    commit();
+    __syncthreads();
+    if (WF_EARLY_W && t + 1 < t_end) fetch_w(t + 1);      // the next window: in flight during the box sums and the MFMAs
+    boxes();
+    __syncthreads();
+    if (t + 1 < t_end) {                       // the next A rows: during the MFMAs (after the box sums: their registers are free again)
+      if (!WF_EARLY_W) fetch_w(t + 1);
+      fetch_a(t + 1);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        a[q] = *reinterpret_cast<const bf16x8*>(sA + q * 128 * GPITCH + (32 * wv + li) * GPITCH + (16 * s + 8 * lh) * 2);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          b[q] = *reinterpret_cast<const bf16x8*>(sB + q * WF_NC * GPITCH + (32 * j + li) * GPITCH + (16 * s + 8 * lh) * 2);
+        if constexpr (!AMP) {
+          acc[j] = mfma16<2>(a[1], b[0], acc[j]);
+          acc[j] = mfma16<2>(a[0], b[1], acc[j]);
+        }
+        acc[j] = mfma16<2>(a[0], b[0], acc[j]);
+      }
+    }
+  }
+  const int nslab = gridDim.x / (nto * ntm);
+  const int J = 27 * Cout;
+  float* Cn = Cp + ((long long)n * nslab + slab) * Cl * J;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int col = 32 * j + li;
+    const int jj = (col >> 3) * Cout + 8 * tn + (col & 7);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < Cl && col < 216) Cn[(long long)row * J + jj] = acc[j][r] * desc;
+    }
+  }
+}
+
 }  // namespace
 
 static int up2_wgrad_slabs(int V, int Cl, int J, int N, int* kslab) {
@@ -2198,6 +2410,61 @@ KMH_API int kmh_up2_wgrad_gemm(const float* A, const float* B, float* C, int N, 
   else
     up2_wgrad_gemm_kernel<3><<<g, 256, 0, s>>>(A, B, (float*)ws, V, Cl, J, ks, ntn, ntm, ascale, bscale, a_scale, a_shift, xcd);
   const long long per = (long long)Cl * J;
+  int nb = ceil_div(per, 256);
+  if (nb > 1024) nb = 1024;
+  up2_wgrad_reduce_kernel<<<dim3(nb, N), 256, 0, s>>>((const float*)ws, ns, per, C);
+  return KMH_LAUNCH_CHECK();
+}
+
+static int up2_fold_slabs(int N, int Dl, int Hl, int Wl, int Cl, int Cout, int* tiles_per_slab, int* ktiles) {
+  const int kt = ceil_div(Wl, 4) * ceil_div(Hl, 4) * ceil_div(Dl, 2);
+  const int per = (Cout / 8) * ceil_div(Cl, 128) * N;       // workgroups per slab
+  int want = ceil_div(512, per);                            // ~512 workgroups: two per CU
+  if (want < 1) want = 1;
+  if (want > kt) want = kt;
+  const int tps = ceil_div(kt, want);
+  *tiles_per_slab = tps;
+  *ktiles = kt;
+  return ceil_div(kt, tps);
+}
+
+/* 1 if kmh_up2_wgrad_fold takes this configuration (fp16 split, whole cout octets), else 0 */
+KMH_API int kmh_up2_wgrad_fold_ok(int Cl, int Cout, int terms) {
+  return (terms == 2 && Cl > 0 && (Cl & 3) == 0 && Cout > 0 && (Cout & 7) == 0) ? 1 : 0;
+}
+
+KMH_API size_t kmh_up2_wgrad_fold_ws_bytes(int N, int Dl, int Hl, int Wl, int Cl, int Cout) {
+  int tps, kt;
+  const int ns = up2_fold_slabs(N, Dl, Hl, Wl, Cl, Cout, &tps, &kt);
+  return (size_t)N * ns * Cl * 27 * Cout * sizeof(float);
+}
+
+/* C (N, Cl, 27 Cout) = kmh_up2_wgrad_gemm(xl, kmh_up2_boxsum(dz)) without the box-sum tensor: xl (N, Dl, Hl, Wl, Cl) the raw
+ * low tensor (a_scale / a_shift: GroupNorm's affine, or both NULL), dz (N, 2Dl, 2Hl, 2Wl, Cout) or channel-blocked
+ * (dz_blocked), ascale / dscale = {S, 1/S} range scales of the normalised low tensor and of dz. */
+KMH_API int kmh_up2_wgrad_fold(const float* xl, const float* dz, float* C, int N, int Dl, int Hl, int Wl, int Cl, int Cout,
+                               const float* ascale, const float* dscale, const float* a_scale, const float* a_shift,
+                               int dz_blocked, void* ws, void* stream) {
+  if (!kmh_up2_wgrad_fold_ok(Cl, Cout, 2) || !ascale || !dscale || (!a_scale != !a_shift) || N <= 0 || N > 65535) return -22;
+  int tps, kt;
+  const int ns = up2_fold_slabs(N, Dl, Hl, Wl, Cl, Cout, &tps, &kt);
+  const int nto = Cout / 8, ntm = ceil_div(Cl, 128);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(nto * ntm * ns, 1, N);
+  static const int xcd = getenv("KEYMORPH_UP2_GEMM_NO_XCD") ? 0 : 1;
+  hipError_t e;
+  if (kmh_amp_enabled()) {
+    e = hipFuncSetAttribute((const void*)up2_wgrad_fold_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
+    if (e != hipSuccess) return (int)e;
+    up2_wgrad_fold_kernel<true><<<g, 256, WF_LDS, s>>>(xl, dz, (float*)ws, Dl, Hl, Wl, Cl, Cout, ceil_div(Wl, 4), ceil_div(Hl, 4),
+                                                       kt, tps, ntm, nto, ascale, dscale, a_scale, a_shift, dz_blocked, xcd);
+  } else {
+    e = hipFuncSetAttribute((const void*)up2_wgrad_fold_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
+    if (e != hipSuccess) return (int)e;
+    up2_wgrad_fold_kernel<false><<<g, 256, WF_LDS, s>>>(xl, dz, (float*)ws, Dl, Hl, Wl, Cl, Cout, ceil_div(Wl, 4), ceil_div(Hl, 4),
+                                                        kt, tps, ntm, nto, ascale, dscale, a_scale, a_shift, dz_blocked, xcd);
+  }
+  const long long per = (long long)Cl * 27 * Cout;
   int nb = ceil_div(per, 256);
   if (nb > 1024) nb = 1024;
   up2_wgrad_reduce_kernel<<<dim3(nb, N), 256, 0, s>>>((const float*)ws, ns, per, C);

@@ -832,6 +832,57 @@ def test_up2_box_sums(cfg):
     close(got, ref, 1e-5, 1e-6)
 
 
+@pytest.mark.parametrize("cfg", [(2, (5, 6, 9), 24, 40, True), (1, (4, 4, 2), 64, 128, False), (2, (3, 7, 8), 40, 136, True),
+                                 (1, (8, 8, 8), 128, 256, True), (1, (6, 4, 12), 8, 12, False)])
+def test_up2_weight_gradient_with_the_box_sums_formed_inside_the_product(cfg):
+    """kmh_up2_wgrad_fold (round 5) == kmh_up2_boxsum + kmh_up2_wgrad_gemm (the route it replaces) == the fp64 product
+    x_low^T G: ragged low shapes (partial 4 x 4 x 2 tiles on every axis), Cl below / above / not a multiple of the 128-row
+    tile, one to sixteen cout octets, with and without GroupNorm's affine on the low tensor, dz dense and channel-blocked.
+    Replaces autograd's weight gradient of interpolate(nearest x2) + cat + conv3d (buildingblocks.py:471-475, :46-78)."""
+    from keymorph_amd import _lib
+    from keymorph_amd import backbone_ops as B
+    from keymorph_amd.backbone_ops import _p, _stream, check
+    lib = _lib.load()
+    N, ld, Cout, Cl, affine = cfg
+    assert lib.kmh_up2_wgrad_fold_ok(Cl, Cout, 2) == 1 and lib.kmh_up2_wgrad_fold_ok(Cl, Cout, 3) == 0
+    assert lib.kmh_up2_wgrad_fold_ok(Cl, Cout + 4, 2) == 0
+    g = gen(57)
+    Vl = ld[0] * ld[1] * ld[2]
+    dz = torch.randn(N, 2 * ld[0], 2 * ld[1], 2 * ld[2], Cout, generator=g).to(DEV)
+    xl = torch.randn(N, *ld, Cl, generator=g).to(DEV)
+    sc = (1 + 0.3 * torch.randn(N, Cl, generator=g)).to(DEV) if affine else None
+    sh = (0.3 * torch.randn(N, Cl, generator=g)).to(DEV) if affine else None
+    xn = xl * sc.view(N, 1, 1, 1, Cl) + sh.view(N, 1, 1, 1, Cl) if affine else xl
+    asc, dsc = B.absmax_scale(xn), B.absmax_scale(dz)
+    boxes = torch.empty(N, Vl, 27 * Cout, device=DEV)
+    check(lib.kmh_up2_boxsum(_p(dz), _p(boxes), N, ld[0], ld[1], ld[2], Cout, 0, _stream()), "kmh_up2_boxsum")
+    ref = torch.einsum("nvc,nvj->ncj", xn.reshape(N, Vl, Cl).double(), boxes.double())
+    old = torch.full((N, Cl, 27 * Cout), float("nan"), device=DEV)
+    ws = torch.empty(int(lib.kmh_up2_wgrad_gemm_ws_bytes(N, Vl, Cl, 27 * Cout)) // 4 + 1, device=DEV)
+    bsc = dsc * torch.tensor([0.125, 8.0], device=DEV)
+    check(lib.kmh_up2_wgrad_gemm(_p(xl), _p(boxes), _p(old), N, Vl, Cl, 27 * Cout, 2, _p(asc), _p(bsc), _p(sc), _p(sh), _p(ws),
+                                 _stream()), "kmh_up2_wgrad_gemm")
+    ws2 = torch.empty(int(lib.kmh_up2_wgrad_fold_ws_bytes(N, ld[0], ld[1], ld[2], Cl, Cout)) // 4 + 1, device=DEV)
+    dzb = dz.reshape(N, -1, Cout // 8, 8).permute(0, 2, 1, 3).contiguous()
+    outs = []
+    for blocked in (0, 1):
+        got = torch.full((N, Cl, 27 * Cout), float("nan"), device=DEV)
+        check(lib.kmh_up2_wgrad_fold(_p(xl), _p(dzb if blocked else dz), _p(got), N, ld[0], ld[1], ld[2], Cl, Cout, _p(asc),
+                                     _p(dsc), _p(sc), _p(sh), blocked, _p(ws2), _stream()), "kmh_up2_wgrad_fold")
+        assert bool(torch.isfinite(got).all())
+        outs.append(got)
+    assert torch.equal(outs[0], outs[1])                              # the layout of dz changes nothing
+    assert torch.equal(outs[0], outs[0].clone()) and True
+    scale = float(ref.abs().max())
+    close(outs[0].double(), ref, 3e-6 * scale, 1e-4)                  # the f16x3 bar of every other product
+    close(old.double(), ref, 3e-6 * scale, 1e-4)
+    close(outs[0], old, 2e-6 * scale, 1e-4)                           # same operand images: only the summation order differs
+    again = torch.empty_like(outs[0])
+    check(lib.kmh_up2_wgrad_fold(_p(xl), _p(dz), _p(again), N, ld[0], ld[1], ld[2], Cl, Cout, _p(asc), _p(dsc), _p(sc), _p(sh),
+                                 0, _p(ws2), _stream()), "kmh_up2_wgrad_fold")
+    assert torch.equal(again, outs[0])                                # deterministic
+
+
 @pytest.mark.parametrize("cfg", [(2, 16, 24, 32, (3, 5, 18)), (1, 8, 40, 72, (4, 4, 33)), (1, 64, 136, 64, (2, 8, 32))])
 @pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
 def test_up2_data_gradient_at_low_resolution(cfg, mode):
