@@ -1576,6 +1576,9 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
     cv_in = cv_brick_next;
     pb ^= 1;
   }
+  // (KMH_S_UNCOND: the last stage requested a "next stage" that does not exist -- nothing may still be in flight to this wave's
+  // registers or to the workgroup's LDS when they are handed to another workgroup)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 static std::atomic<int> g_amp{-1};
@@ -2173,6 +2176,9 @@ __global__ __launch_bounds__(256) void up2_wgrad_reduce_kernel(const float* __re
 // 1.91 -> 1.40 ms.  With the box sums AND the MFMAs compiled out a launch still takes 2.08 / 1.03 ms: the kernel is bound by what
 // a CU can load (window 19.2 KB + A rows 16 KB per step: 9.2 GB per launch, mostly L2 hits, at ~ 10 B / cycle / CU); the box sums
 // add 0.5 ms, the MFMAs 0.25.  Fetching the window before or after the box sums: no difference.
+#ifndef WF_DMA                 // 1 = the dz window by LDS-DMA (0: through registers, the A/B arm)
+#define WF_DMA 1
+#endif
 #ifndef WF_EARLY_W
 #define WF_EARLY_W 1
 #endif
@@ -2184,7 +2190,7 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_fold_kernel(
     const float* __restrict__ xl, const float* __restrict__ dz, float* __restrict__ Cp, int Dl, int Hl, int Wl, int Cl, int Cout,
     int tiles_x, int tiles_y, int ktiles, int tiles_per_slab, int ntm, int nto, const float* __restrict__ ascale,
     const float* __restrict__ dscale, const float* __restrict__ a_scale, const float* __restrict__ a_shift, int dz_blocked,
-    int xcd) {
+    int xcd, const float* __restrict__ zero16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wf_lds[];
   float4* sW = reinterpret_cast<float4*>(wf_lds);                                   // [voxel][2 quads]
   unsigned char* sA = wf_lds + WF_VOX * 2 * 16;                                     // [2 terms][128 rows][GPITCH]
@@ -2226,11 +2232,17 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_fold_kernel(
       const int e = tid + i * 256, q = e & 1, v = e >> 1;
       const int lx = v % WF_HX, ly = (v / WF_HX) % WF_HY, lz = v / (WF_HX * WF_HY);
       const int ux = wx + lx, uy = wy + ly, uz = wz + lz;
-      pw[i] = z4;
-      if (e < 2 * WF_VOX && (unsigned)ux < (unsigned)W && (unsigned)uy < (unsigned)H && (unsigned)uz < (unsigned)D) {
-        const long long vox = ((long long)uz * H + uy) * W + ux;
-        const float* src = dz_blocked ? dn + ((long long)tn * Vh + vox) * 8 + 4 * q : dn + vox * Cout + 8 * tn + 4 * q;
-        pw[i] = *reinterpret_cast<const float4*>(src);
+      const bool in = e < 2 * WF_VOX && (unsigned)ux < (unsigned)W && (unsigned)uy < (unsigned)H && (unsigned)uz < (unsigned)D;
+      const long long vox = in ? ((long long)uz * H + uy) * W + ux : 0;
+      const float* src = dz_blocked ? dn + ((long long)tn * Vh + vox) * 8 + 4 * q : dn + vox * Cout + 8 * tn + 4 * q;
+      if constexpr (WF_DMA != 0) {
+        // straight into the window (element e = lane-linear: 16 bytes per lane behind a wave-uniform base), no staging
+        // registers; voxels outside the volume copy 16 bytes of zeros.  (i = 4: only the first 176 elements exist -- the
+        // other lanes must not write: what follows the window in LDS is the A image)
+        if (e < 2 * WF_VOX)
+          __builtin_amdgcn_global_load_lds((kmh_glb_ptr)(in ? src : zero16), (kmh_lds_ptr)(sW + i * 256 + wv * 64), 16, 0, 0);
+      } else {
+        pw[i] = in ? *reinterpret_cast<const float4*>(src) : z4;
       }
     }
   };
@@ -2255,10 +2267,12 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_fold_kernel(
     sC[128 + tid] = (a_scale && ca < Cl) ? a_shift[(long long)n * Cl + ca] : 0.f;
   }
   auto commit = [&]() {                                   // registers -> the window and the A image (tile x0, y0, z0)
+    if constexpr (WF_DMA == 0) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int e = tid + i * 256;
-      if (e < 2 * WF_VOX) sW[e] = pw[i];
+      for (int i = 0; i < 5; ++i) {
+        const int e = tid + i * 256;
+        if (e < 2 * WF_VOX) sW[e] = pw[i];
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -2329,12 +2343,13 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_fold_kernel(
   for (int t = t_beg; t < t_end; ++t) {
     __syncthreads();                           // the previous step's fragment reads are done
     commit();
+    if (WF_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's pieces of the window are in LDS
     __syncthreads();
-    if (WF_EARLY_W && t + 1 < t_end) fetch_w(t + 1);      // the next window: in flight during the box sums and the MFMAs
+    if (!WF_DMA && WF_EARLY_W && t + 1 < t_end) fetch_w(t + 1);      // the next window: in flight during the box sums and the MFMAs
     boxes();
     __syncthreads();
     if (t + 1 < t_end) {                       // the next A rows: during the MFMAs (after the box sums: their registers are free again)
-      if (!WF_EARLY_W) fetch_w(t + 1);
+      if (WF_DMA || !WF_EARLY_W) fetch_w(t + 1);
       fetch_a(t + 1);
     }
 #pragma unroll
@@ -2453,16 +2468,23 @@ KMH_API int kmh_up2_wgrad_fold(const float* xl, const float* dz, float* C, int N
   dim3 g(nto * ntm * ns, 1, N);
   static const int xcd = getenv("KEYMORPH_UP2_GEMM_NO_XCD") ? 0 : 1;
   hipError_t e;
+  static float* zero16[64] = {nullptr};                     // per device: 256 bytes of zeros, the source of voxels outside the volume
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -22;
+  if (!zero16[dev]) {
+    if (hipMalloc(&zero16[dev], 256) != hipSuccess) return -12;
+    if (hipMemset(zero16[dev], 0, 256) != hipSuccess) return -12;
+  }
   if (kmh_amp_enabled()) {
     e = hipFuncSetAttribute((const void*)up2_wgrad_fold_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
     if (e != hipSuccess) return (int)e;
     up2_wgrad_fold_kernel<true><<<g, 256, WF_LDS, s>>>(xl, dz, (float*)ws, Dl, Hl, Wl, Cl, Cout, ceil_div(Wl, 4), ceil_div(Hl, 4),
-                                                       kt, tps, ntm, nto, ascale, dscale, a_scale, a_shift, dz_blocked, xcd);
+                                                       kt, tps, ntm, nto, ascale, dscale, a_scale, a_shift, dz_blocked, xcd, zero16[dev]);
   } else {
     e = hipFuncSetAttribute((const void*)up2_wgrad_fold_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
     if (e != hipSuccess) return (int)e;
     up2_wgrad_fold_kernel<false><<<g, 256, WF_LDS, s>>>(xl, dz, (float*)ws, Dl, Hl, Wl, Cl, Cout, ceil_div(Wl, 4), ceil_div(Hl, 4),
-                                                        kt, tps, ntm, nto, ascale, dscale, a_scale, a_shift, dz_blocked, xcd);
+                                                        kt, tps, ntm, nto, ascale, dscale, a_scale, a_shift, dz_blocked, xcd, zero16[dev]);
   }
   const long long per = (long long)Cl * 27 * Cout;
   int nb = ceil_div(per, 256);
