@@ -1421,8 +1421,12 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
       // this single wave per SIMD is latency-bound there).  Planes wz (even) and wz + 1 hold the z children: odd planes publish
       // through LDS.  Scan order of the reference (z, y, x; a later value wins only if strictly greater, or NaN): lower-index
       // halves are combined first -- the same winners as kmh_maxpool3d_fwd.
+      // (after a ReLU no value is NaN -- v_max_f32 returns its other operand -- and ATen's "a NaN wins" test, one unordered compare
+      // and one mask OR per comparison, 274 of the epilogue's ~ 2000 instructions, is compiled out: two instances of the block)
+      auto pool_block = [&](auto nan_wins) {
+      constexpr bool NANW = decltype(nan_wins)::value;
       auto pick = [](float a, float b, unsigned ca, unsigned cb, float& m_, unsigned& c_) {
-        const bool tb = (b > a) || (b != b);
+        const bool tb = (b > a) || (NANW && (b != b));
         m_ = tb ? b : a; c_ = tb ? cb : ca;
       };
       const int cl = co0 + li;
@@ -1502,6 +1506,9 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
           }
         }
       }
+      };
+      if (relu_out) pool_block(std::false_type{});
+      else pool_block(std::true_type{});
     } else {
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
