@@ -2191,24 +2191,43 @@ __global__ __launch_bounds__(256) void up2_wgrad_reduce_kernel(const float* __re
 #endif
 constexpr int WF_HX = 10, WF_HY = 10, WF_HZ = 6, WF_VOX = WF_HX * WF_HY * WF_HZ;      // window of a 4 x 4 x 2 low tile
 constexpr int WF_NC = 224;                                                           // 216 columns, padded to 7 x 32
-constexpr int WF_LDS = WF_VOX * 2 * 16 + 2 * 128 * GPITCH + 2 * WF_NC * GPITCH + 1024;      // 19200 + 20480 + 35840 + 1024
-template <bool AMP>
-__global__ __launch_bounds__(256, 2) void up2_wgrad_fold_kernel(
+// MODE (round 5, last): the kernel is bound by what a CU can load, so two of its workgroups become the two halves of ONE
+// 512-thread workgroup that share what they both read: MODE 1 = two cout octets over the same A rows (one A image, two windows
+// and B images: 54.4 KB of loads per step instead of 70.4), MODE 2 = two 128-row tiles over the same window and box sums (one
+// window and B image, two A images: 51.2 KB, and half the box-sum work).  MODE 0 = the 256-thread kernel, two per CU.
+// Measured (profiles/r5y_up2_wgrad_fold_modes.txt): MODE 2 -5 % where it applies (256 -> 128 at 64^3: 1.38 -> 1.31 ms); MODE 1
+// +3 % (128 -> 64 at 128^3: 2.79 -> 2.88 ms: 23 % fewer bytes, but one workgroup's phases no longer overlap another's) -- it is
+// compiled, tested and selectable (KEYMORPH_UP2_FOLD_MODE=1), not chosen.
+template <int MODE>
+constexpr int wf_lds_bytes() {
+  constexpr int NW = MODE == 1 ? 2 : 1, NA = MODE == 2 ? 2 : 1;
+  return NW * (WF_VOX * 2 * 16 + 2 * WF_NC * GPITCH) + NA * (2 * 128 * GPITCH + 1024);
+}
+template <bool AMP, int MODE>
+__global__ __launch_bounds__(MODE ? 512 : 256, MODE ? 1 : 2) void up2_wgrad_fold_kernel(
     const float* __restrict__ xl, const float* __restrict__ dz, float* __restrict__ Cp, int Dl, int Hl, int Wl, int Cl, int Cout,
-    int tiles_x, int tiles_y, int ktiles, int tiles_per_slab, int ntm, int nto, const float* __restrict__ ascale,
-    const float* __restrict__ dscale, const float* __restrict__ a_scale, const float* __restrict__ a_shift, int dz_blocked,
-    int xcd, const float* __restrict__ zero16) {
+    int tiles_x, int tiles_y, int ktiles, int tiles_per_slab, int ntm /* grid row tiles */, int nto /* grid column groups */,
+    const float* __restrict__ ascale, const float* __restrict__ dscale, const float* __restrict__ a_scale,
+    const float* __restrict__ a_shift, int dz_blocked, int xcd, const float* __restrict__ zero16) {
+  constexpr int NW = MODE == 1 ? 2 : 1, NA = MODE == 2 ? 2 : 1;          // windows + B images, A images
+  constexpr int TPBF = MODE ? 512 : 256;
+  constexpr int W_BYTES = WF_VOX * 2 * 16, A_BYTES = 2 * 128 * GPITCH, B_BYTES = 2 * WF_NC * GPITCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char wf_lds[];
-  float4* sW = reinterpret_cast<float4*>(wf_lds);                                   // [voxel][2 quads]
-  unsigned char* sA = wf_lds + WF_VOX * 2 * 16;                                     // [2 terms][128 rows][GPITCH]
-  unsigned char* sB = sA + 2 * 128 * GPITCH;                                        // [2 terms][224 rows][GPITCH]
+  unsigned char* sW0 = wf_lds;                                                      // [NW][voxel][2 quads] fp32
+  unsigned char* sA0 = sW0 + NW * W_BYTES;                                          // [NA][2 terms][128 rows][GPITCH]
+  unsigned char* sB0 = sA0 + NA * A_BYTES;                                          // [NW][2 terms][224 rows][GPITCH]
+  float* sC0 = reinterpret_cast<float*>(sB0 + NW * B_BYTES);                        // [NA][2][128]: GroupNorm's affine of the A rows
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int hf = MODE ? tid >> 8 : 0, t8 = tid & 255;                               // the thread's half, its index in it
+  const int hw = MODE ? wv >> 2 : 0, wq = wv & 3;                                   // the wave's half, its 32-row tile
   const int n = blockIdx.z;
   int item = xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-  const int tn = item % nto; item /= nto;                 // the cout octet (the octets of one K slab read the same rows of xl)
+  const int tn = item % nto; item /= nto;                 // column group (the groups of one K slab read the same rows of xl)
   const int tm = item % ntm;
   const int slab = item / ntm;
-  const int m0 = tm * 128;
+  const int oct_t = MODE == 1 ? 2 * tn + hf : tn, oct_w = MODE == 1 ? 2 * tn + hw : tn;              // cout octet: staged / multiplied
+  const int m0_t = (MODE == 2 ? 2 * tm + hf : tm) * 128, m0_w = (MODE == 2 ? 2 * tm + hw : tm) * 128;  // first row: staged / multiplied
+  const int iw_t = MODE == 1 ? hf : 0, ia_t = MODE == 2 ? hf : 0;                   // the images this thread stages into
   const int D = 2 * Dl, H = 2 * Hl, W = 2 * Wl;
   const long long Vl = (long long)Dl * Hl * Wl, Vh = (long long)D * H * W;
   const float sa = ascale[0], sb = dscale[0] * 0.125f;                             // box sums: |sum of 8| <= 8 max|dz|
@@ -2220,34 +2239,37 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_fold_kernel(
   for (int j = 0; j < 7; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  for (int e = tid; e < 2 * 8 * GPITCH / 4; e += 256) {                             // columns 216 .. 223 stay zero
-    const int t = e / (8 * GPITCH / 4), w = e % (8 * GPITCH / 4);
-    reinterpret_cast<unsigned*>(sB + t * WF_NC * GPITCH + 216 * GPITCH)[w] = 0u;
+  for (int e = tid; e < NW * 2 * 8 * GPITCH / 4; e += TPBF) {                       // columns 216 .. 223 stay zero
+    const int im = e / (2 * 8 * GPITCH / 4), r = e % (2 * 8 * GPITCH / 4), t = r / (8 * GPITCH / 4), w = r % (8 * GPITCH / 4);
+    reinterpret_cast<unsigned*>(sB0 + im * B_BYTES + t * WF_NC * GPITCH + 216 * GPITCH)[w] = 0u;
   }
   const int t_beg = slab * tiles_per_slab;
   int t_end = t_beg + tiles_per_slab;
   if (t_end > ktiles) t_end = ktiles;
-  // staging registers: the window (600 voxels x 2 quads = 1200 float4: 5 per thread), the A rows (16 voxel pairs x 32 quads)
-  float4 pw[5], pa[2][2];
+  // staging: the window (600 voxels x 2 quads = 1200 float4) by LDS-DMA, the A rows (16 voxel pairs x 32 quads) through registers
+  constexpr int NIW = MODE == 2 ? 3 : 5;                                            // window elements per thread
+  constexpr int NIA = MODE == 1 ? 1 : 2;                                            // A items per thread
+  float4 pw[WF_DMA ? 1 : NIW], pa[NIA][2];
   int x0 = 0, y0 = 0, z0 = 0;                                                       // the tile the registers hold
   auto fetch_w = [&](int t) {                             // the window of tile t
     const int bx = t % tiles_x, by = (t / tiles_x) % tiles_y, bz = t / (tiles_x * tiles_y);
     const int wx = 8 * bx - 1, wy = 8 * by - 1, wz = 4 * bz - 1;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* sWt = reinterpret_cast<float4*>(sW0 + iw_t * W_BYTES);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int e = tid + i * 256, q = e & 1, v = e >> 1;
+    for (int i = 0; i < NIW; ++i) {
+      const int e = (MODE == 2 ? tid + i * 512 : t8 + i * 256), q = e & 1, v = e >> 1;
       const int lx = v % WF_HX, ly = (v / WF_HX) % WF_HY, lz = v / (WF_HX * WF_HY);
       const int ux = wx + lx, uy = wy + ly, uz = wz + lz;
       const bool in = e < 2 * WF_VOX && (unsigned)ux < (unsigned)W && (unsigned)uy < (unsigned)H && (unsigned)uz < (unsigned)D;
       const long long vox = in ? ((long long)uz * H + uy) * W + ux : 0;
-      const float* src = dz_blocked ? dn + ((long long)tn * Vh + vox) * 8 + 4 * q : dn + vox * Cout + 8 * tn + 4 * q;
+      const float* src = dz_blocked ? dn + ((long long)oct_t * Vh + vox) * 8 + 4 * q : dn + vox * Cout + 8 * oct_t + 4 * q;
       if constexpr (WF_DMA != 0) {
         // straight into the window (element e = lane-linear: 16 bytes per lane behind a wave-uniform base), no staging
-        // registers; voxels outside the volume copy 16 bytes of zeros.  (i = 4: only the first 176 elements exist -- the
-        // other lanes must not write: what follows the window in LDS is the A image)
+        // registers; voxels outside the volume copy 16 bytes of zeros.  (Past element 1199 a lane must not write: what
+        // follows the window in LDS is another image.)
         if (e < 2 * WF_VOX)
-          __builtin_amdgcn_global_load_lds((kmh_glb_ptr)(in ? src : zero16), (kmh_lds_ptr)(sW + i * 256 + wv * 64), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((kmh_glb_ptr)(in ? src : zero16), (kmh_lds_ptr)(sWt + (e - lane)), 16, 0, 0);
       } else {
         pw[i] = in ? *reinterpret_cast<const float4*>(src) : z4;
       }
@@ -2258,32 +2280,35 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_fold_kernel(
     x0 = 4 * bx; y0 = 4 * by; z0 = 2 * bz;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + i * 256, cq = (e & 7) + 8 * (e >> 7), kp = (e >> 3) & 15;      // 8 lanes: one 128-byte line of a voxel row
-      const int k = 2 * kp, gx = x0 + (k & 3), gy = y0 + ((k >> 2) & 3), gz = z0 + (k >> 4), ca = m0 + 4 * cq;
+    for (int i = 0; i < NIA; ++i) {
+      const int e = (MODE == 1 ? tid : t8 + i * 256), cq = (e & 7) + 8 * (e >> 7), kp = (e >> 3) & 15;      // 8 lanes: one 128-byte line of a voxel row
+      const int k = 2 * kp, gx = x0 + (k & 3), gy = y0 + ((k >> 2) & 3), gz = z0 + (k >> 4), ca = m0_t + 4 * cq;
       const bool rowok = gy < Hl && gz < Dl && ca < Cl;
       const float* src = xn + (((long long)gz * Hl + gy) * Wl + gx) * Cl + ca;
       pa[i][0] = (rowok && gx < Wl) ? *reinterpret_cast<const float4*>(src) : z4;
       pa[i][1] = (rowok && gx + 1 < Wl) ? *reinterpret_cast<const float4*>(src + Cl) : z4;
     }
   };
-  float* sC = reinterpret_cast<float*>(sB + 2 * WF_NC * GPITCH);                     // GroupNorm's affine of the A rows: [2][128]
-  if (tid < 128) {
-    const int ca = m0 + tid;
-    sC[tid] = (a_scale && ca < Cl) ? a_scale[(long long)n * Cl + ca] : 1.f;
-    sC[128 + tid] = (a_scale && ca < Cl) ? a_shift[(long long)n * Cl + ca] : 0.f;
+  if ((MODE == 2 ? t8 : tid) < 128) {
+    const int c = MODE == 2 ? t8 : tid, ca = m0_t + c;
+    float* sC = sC0 + ia_t * 256;
+    sC[c] = (a_scale && ca < Cl) ? a_scale[(long long)n * Cl + ca] : 1.f;
+    sC[128 + c] = (a_scale && ca < Cl) ? a_shift[(long long)n * Cl + ca] : 0.f;
   }
   auto commit = [&]() {                                   // registers -> the window and the A image (tile x0, y0, z0)
     if constexpr (WF_DMA == 0) {
+      float4* sWt = reinterpret_cast<float4*>(sW0 + iw_t * W_BYTES);
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int e = tid + i * 256;
-        if (e < 2 * WF_VOX) sW[e] = pw[i];
+      for (int i = 0; i < NIW; ++i) {
+        const int e = (MODE == 2 ? tid + i * 512 : t8 + i * 256);
+        if (e < 2 * WF_VOX) sWt[e] = pw[i];
       }
     }
+    unsigned char* sA = sA0 + ia_t * A_BYTES;
+    const float* sC = sC0 + ia_t * 256;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + i * 256, cq = (e & 7) + 8 * (e >> 7), kp = (e >> 3) & 15;
+    for (int i = 0; i < NIA; ++i) {
+      const int e = (MODE == 1 ? tid : t8 + i * 256), cq = (e & 7) + 8 * (e >> 7), kp = (e >> 3) & 15;
       const int k = 2 * kp, gx = x0 + (k & 3), gy = y0 + ((k >> 2) & 3), gz = z0 + (k >> 4);
       const bool rowok = gy < Hl && gz < Dl;
       const bool v0 = rowok && gx < Wl, v1 = rowok && gx + 1 < Wl;              // voxels past the volume: zero rows (no shift)
@@ -2302,8 +2327,11 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_fold_kernel(
     }
   };
   auto boxes = [&]() {                                    // window -> the B image: thread = (low voxel m, kz, channel quad q)
-    if (tid >= 192) return;
-    const int q = tid & 1, kz = (tid >> 1) % 3, m = tid / 6;
+    const int bt = MODE == 1 ? t8 : tid;                  // (MODE 1: 192 threads of each half; else the first 192 of the workgroup)
+    if (bt >= 192) return;
+    const float4* sW = reinterpret_cast<const float4*>(sW0 + iw_t * W_BYTES);
+    unsigned char* sB = sB0 + iw_t * B_BYTES;
+    const int q = bt & 1, kz = (bt >> 1) % 3, m = bt / 6;
     const int lmx = m & 3, lmy = (m >> 2) & 3, lmz = m >> 4;
     float4 Y[3][3];
 #pragma unroll
@@ -2347,6 +2375,8 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_fold_kernel(
     }
   };
   if (t_beg < t_end) { fetch_w(t_beg); fetch_a(t_beg); }
+  const unsigned char* sAw = sA0 + (MODE == 2 ? hw : 0) * A_BYTES;                  // the images this wave multiplies
+  const unsigned char* sBw = sB0 + (MODE == 1 ? hw : 0) * B_BYTES;
   for (int t = t_beg; t < t_end; ++t) {
     __syncthreads();                           // the previous step's fragment reads are done
     commit();
@@ -2364,12 +2394,12 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_fold_kernel(
       bf16x8 a[2], b[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q)
-        a[q] = *reinterpret_cast<const bf16x8*>(sA + q * 128 * GPITCH + (32 * wv + li) * GPITCH + (16 * s + 8 * lh) * 2);
+        a[q] = *reinterpret_cast<const bf16x8*>(sAw + q * 128 * GPITCH + (32 * wq + li) * GPITCH + (16 * s + 8 * lh) * 2);
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-          b[q] = *reinterpret_cast<const bf16x8*>(sB + q * WF_NC * GPITCH + (32 * j + li) * GPITCH + (16 * s + 8 * lh) * 2);
+          b[q] = *reinterpret_cast<const bf16x8*>(sBw + q * WF_NC * GPITCH + (32 * j + li) * GPITCH + (16 * s + 8 * lh) * 2);
         if constexpr (!AMP) {
           acc[j] = mfma16<2>(a[1], b[0], acc[j]);
           acc[j] = mfma16<2>(a[0], b[1], acc[j]);
@@ -2384,10 +2414,10 @@ __global__ __launch_bounds__(256, 2) void up2_wgrad_fold_kernel(
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     const int col = 32 * j + li;
-    const int jj = (col >> 3) * Cout + 8 * tn + (col & 7);
+    const int jj = (col >> 3) * Cout + 8 * oct_w + (col & 7);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int row = m0_w + 32 * wq + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (row < Cl && col < 216) Cn[(long long)row * J + jj] = acc[j][r] * desc;
     }
   }
@@ -2438,10 +2468,24 @@ KMH_API int kmh_up2_wgrad_gemm(const float* A, const float* B, float* C, int N, 
   return KMH_LAUNCH_CHECK();
 }
 
+// which fold kernel: 2 = two row tiles per workgroup (Cl > 128 with an even tile count), 1 = two cout octets, 0 = the 256-thread one
+// (KEYMORPH_UP2_FOLD_MODE=0|1|2 forces one where it applies: A/B runs)
+static int up2_fold_mode(int Cl, int Cout) {
+  const int ntm = ceil_div(Cl, 128), nto = Cout / 8;
+  int mode = (ntm % 2 == 0) ? 2 : 0;      // (MODE 1 measured 3 % SLOWER than two 256-thread workgroups per CU: forced only)
+  const char* env = getenv("KEYMORPH_UP2_FOLD_MODE");       // (read per call: the tests switch it)
+  if (env) {
+    const int want = atoi(env);
+    if (want == 0 || (want == 1 && nto % 2 == 0) || (want == 2 && ntm % 2 == 0)) mode = want;
+  }
+  return mode;
+}
+
 static int up2_fold_slabs(int N, int Dl, int Hl, int Wl, int Cl, int Cout, int* tiles_per_slab, int* ktiles) {
   const int kt = ceil_div(Wl, 4) * ceil_div(Hl, 4) * ceil_div(Dl, 2);
-  const int per = (Cout / 8) * ceil_div(Cl, 128) * N;       // workgroups per slab
-  int want = ceil_div(512, per);                            // ~512 workgroups: two per CU
+  const int mode = up2_fold_mode(Cl, Cout);
+  const int per = (Cout / 8) * ceil_div(Cl, 128) * N / (mode ? 2 : 1);       // workgroups per slab
+  int want = ceil_div(mode ? 256 : 512, per);               // one 512-thread or two 256-thread workgroups per CU
   if (want < 1) want = 1;
   if (want > kt) want = kt;
   const int tps = ceil_div(kt, want);
@@ -2461,6 +2505,19 @@ KMH_API size_t kmh_up2_wgrad_fold_ws_bytes(int N, int Dl, int Hl, int Wl, int Cl
   return (size_t)N * ns * Cl * 27 * Cout * sizeof(float);
 }
 
+template <bool AMP, int MODE>
+static int launch_up2_fold(dim3 g, hipStream_t s, const float* xl, const float* dz, float* ws, int Dl, int Hl, int Wl, int Cl, int Cout,
+                           int kt, int tps, int ntm, int nto, const float* ascale, const float* dscale, const float* a_scale,
+                           const float* a_shift, int dz_blocked, int xcd, const float* zero16) {
+  constexpr int lds = wf_lds_bytes<MODE>();
+  hipError_t e = hipFuncSetAttribute((const void*)up2_wgrad_fold_kernel<AMP, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return (int)e;
+  up2_wgrad_fold_kernel<AMP, MODE><<<g, MODE ? 512 : 256, lds, s>>>(xl, dz, ws, Dl, Hl, Wl, Cl, Cout, ceil_div(Wl, 4), ceil_div(Hl, 4),
+                                                                  kt, tps, ntm, nto, ascale, dscale, a_scale, a_shift, dz_blocked,
+                                                                  xcd, zero16);
+  return 0;
+}
+
 /* C (N, Cl, 27 Cout) = kmh_up2_wgrad_gemm(xl, kmh_up2_boxsum(dz)) without the box-sum tensor: xl (N, Dl, Hl, Wl, Cl) the raw
  * low tensor (a_scale / a_shift: GroupNorm's affine, or both NULL), dz (N, 2Dl, 2Hl, 2Wl, Cout) or channel-blocked
  * (dz_blocked), ascale / dscale = {S, 1/S} range scales of the normalised low tensor and of dz. */
@@ -2470,11 +2527,11 @@ KMH_API int kmh_up2_wgrad_fold(const float* xl, const float* dz, float* C, int N
   if (!kmh_up2_wgrad_fold_ok(Cl, Cout, 2) || !ascale || !dscale || (!a_scale != !a_shift) || N <= 0 || N > 65535) return -22;
   int tps, kt;
   const int ns = up2_fold_slabs(N, Dl, Hl, Wl, Cl, Cout, &tps, &kt);
-  const int nto = Cout / 8, ntm = ceil_div(Cl, 128);
+  const int mode = up2_fold_mode(Cl, Cout);
+  const int nto = (Cout / 8) / (mode == 1 ? 2 : 1), ntm = ceil_div(Cl, 128) / (mode == 2 ? 2 : 1);      // as the grid sees them
   hipStream_t s = (hipStream_t)stream;
   dim3 g(nto * ntm * ns, 1, N);
   static const int xcd = getenv("KEYMORPH_UP2_GEMM_NO_XCD") ? 0 : 1;
-  hipError_t e;
   static float* zero16[64] = {nullptr};                     // per device: 256 bytes of zeros, the source of voxels outside the volume
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -22;
@@ -2482,17 +2539,15 @@ KMH_API int kmh_up2_wgrad_fold(const float* xl, const float* dz, float* C, int N
     if (hipMalloc(&zero16[dev], 256) != hipSuccess) return -12;
     if (hipMemset(zero16[dev], 0, 256) != hipSuccess) return -12;
   }
-  if (kmh_amp_enabled()) {
-    e = hipFuncSetAttribute((const void*)up2_wgrad_fold_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
-    if (e != hipSuccess) return (int)e;
-    up2_wgrad_fold_kernel<true><<<g, 256, WF_LDS, s>>>(xl, dz, (float*)ws, Dl, Hl, Wl, Cl, Cout, ceil_div(Wl, 4), ceil_div(Hl, 4),
-                                                       kt, tps, ntm, nto, ascale, dscale, a_scale, a_shift, dz_blocked, xcd, zero16[dev]);
-  } else {
-    e = hipFuncSetAttribute((const void*)up2_wgrad_fold_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
-    if (e != hipSuccess) return (int)e;
-    up2_wgrad_fold_kernel<false><<<g, 256, WF_LDS, s>>>(xl, dz, (float*)ws, Dl, Hl, Wl, Cl, Cout, ceil_div(Wl, 4), ceil_div(Hl, 4),
-                                                        kt, tps, ntm, nto, ascale, dscale, a_scale, a_shift, dz_blocked, xcd, zero16[dev]);
-  }
+  const bool amp = kmh_amp_enabled();
+  int rc;
+#define KMH_FOLD(A, M) launch_up2_fold<A, M>(g, s, xl, dz, (float*)ws, Dl, Hl, Wl, Cl, Cout, kt, tps, ntm, nto, ascale, dscale, \
+                                             a_scale, a_shift, dz_blocked, xcd, zero16[dev])
+  if (mode == 2) rc = amp ? KMH_FOLD(true, 2) : KMH_FOLD(false, 2);
+  else if (mode == 1) rc = amp ? KMH_FOLD(true, 1) : KMH_FOLD(false, 1);
+  else rc = amp ? KMH_FOLD(true, 0) : KMH_FOLD(false, 0);
+#undef KMH_FOLD
+  if (rc) return rc;
   const long long per = (long long)Cl * 27 * Cout;
   int nb = ceil_div(per, 256);
   if (nb > 1024) nb = 1024;

@@ -834,7 +834,8 @@ def test_up2_box_sums(cfg):
 
 @pytest.mark.parametrize("cfg", [(2, (5, 6, 9), 24, 40, True), (1, (4, 4, 2), 64, 128, False), (2, (3, 7, 8), 40, 136, True),
                                  (1, (8, 8, 8), 128, 256, True), (1, (6, 4, 12), 8, 12, False)])
-def test_up2_weight_gradient_with_the_box_sums_formed_inside_the_product(cfg):
+@pytest.mark.parametrize("force", [None, "0", "1", "2"])
+def test_up2_weight_gradient_with_the_box_sums_formed_inside_the_product(cfg, force, monkeypatch):
     """kmh_up2_wgrad_fold (round 5) == kmh_up2_boxsum + kmh_up2_wgrad_gemm (the route it replaces) == the fp64 product
     x_low^T G: ragged low shapes (partial 4 x 4 x 2 tiles on every axis), Cl below / above / not a multiple of the 128-row
     tile, one to sixteen cout octets, with and without GroupNorm's affine on the low tensor, dz dense and channel-blocked.
@@ -844,6 +845,12 @@ def test_up2_weight_gradient_with_the_box_sums_formed_inside_the_product(cfg):
     from keymorph_amd.backbone_ops import _p, _stream, check
     lib = _lib.load()
     N, ld, Cout, Cl, affine = cfg
+    # the kernel's three shapes: 256 threads (two workgroups per CU), 512 threads = two cout octets over one A image, 512 threads
+    # = two 128-row tiles over one window; None = the library's own choice, a forced one applies where the shape allows it
+    if force is None:
+        monkeypatch.delenv("KEYMORPH_UP2_FOLD_MODE", raising=False)
+    else:
+        monkeypatch.setenv("KEYMORPH_UP2_FOLD_MODE", force)
     assert lib.kmh_up2_wgrad_fold_ok(Cl, Cout, 2) == 1 and lib.kmh_up2_wgrad_fold_ok(Cl, Cout, 3) == 0
     assert lib.kmh_up2_wgrad_fold_ok(Cl, Cout + 4, 2) == 0
     g = gen(57)
