@@ -498,8 +498,8 @@ def main():
                                           max(pa.get("kmh_conv3d_wgrad_bf", {}).get("ms", 0), 1e-9) / 1e9,
                       "amp_note": f"KeyMorph(use_amp=True) (keymorph/model.py:176-191 autocasts the extractor to fp16): the 27-tap "
                                   f"forward / data-gradient kernels, the weight gradient and the fused decoder operator multiply "
-                                  f"fp16 hi terms only (fp32 accumulation and tensors); first layer, head, aligner, warp and loss "
-                                  f"unchanged; {a.amp} timed step(s); NOT the headline (a reduced-precision configuration)"})
+                                  f"fp16 hi terms only (fp32 accumulation and tensors), and so do the fused head's forward and "
+                                  f"its two masked backward kernels; first layer, aligner, warp and loss unchanged; {a.amp} timed step(s); NOT the headline (a reduced-precision configuration)"})
 
     def agree(ok):
         """True iff every rank says ok (one MIN all-reduce; ranks must reach this together)"""

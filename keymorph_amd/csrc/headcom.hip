@@ -391,15 +391,19 @@ __device__ __forceinline__ void split4(const float4 v, uint2 out[TERMS]) {
     out[t].y = h[2] | (h[3] << 16);
   }
 }
-template <int TERMS>
+// AMP (KeyMorph(use_amp=True), kmh_conv_set_amp; TERMS == 2 only): the hi x hi product alone, as the reference's autocast
+// runs this convolution in fp16 (keymorph/model.py:176-191)
+template <int TERMS, bool AMP = false>
 __device__ __forceinline__ f32x16 mfma_split(const bf16x8 a[TERMS], const bf16x8 b[TERMS], f32x16 acc) {
   if constexpr (TERMS == 3) {
     acc = mfma16<TERMS>(a[2], b[0], acc);
     acc = mfma16<TERMS>(a[1], b[1], acc);
     acc = mfma16<TERMS>(a[0], b[2], acc);
   }
-  acc = mfma16<TERMS>(a[1], b[0], acc);
-  acc = mfma16<TERMS>(a[0], b[1], acc);
+  if constexpr (!(AMP && TERMS == 2)) {
+    acc = mfma16<TERMS>(a[1], b[0], acc);
+    acc = mfma16<TERMS>(a[0], b[1], acc);
+  }
   acc = mfma16<TERMS>(a[0], b[0], acc);
   return acc;
 }
@@ -545,7 +549,7 @@ constexpr int WVT = 64;    // dW kernel: voxels per tile (its transposed image h
 // NWV waves per workgroup = 32 NWV keypoint channels share one staged (converted) feature tile: 4 (128 channels, 3
 // workgroups per CU) or 16 (all 512 channels of the headline config on one tile image -- the conversion, which is
 // what bounds these kernels, is then done once per tile instead of once per 128-channel group).
-template <int TERMS, bool ROWS, int NWV>
+template <int TERMS, bool ROWS, int NWV, bool AMP = false>
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 1) void headcom_fwd_bf_kernel(const float* __restrict__ feat,
                                                                  const __bf16* __restrict__ wk,
                                                                  const float* __restrict__ bias,
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 1) void headcom_fwd_bf_ker
 #pragma unroll
           for (int t = 0; t < TERMS; ++t)
             a[t] = *reinterpret_cast<const bf16x8*>(sF + t * (FVT * 128) + swz(32 * vb + li, 2 * s + lh));
-          acc = mfma_split<TERMS>(a, bw[s], acc);
+          acc = mfma_split<TERMS, AMP>(a, bw[s], acc);
         }
       }
       if (ROWS) {
@@ -1008,7 +1012,7 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_bf_kernel(const fl
 // (r & 3) + 8 (r >> 2) + 4 lh: v_bfe_i32 (0 / -1) + v_and per element.
 // WIDE: Cin > 32 (compile time: a run-time test around the second accumulator tile's products makes the compiler shuffle
 // whole accumulator tiles between registers).
-template <int TERMS, int NWV, bool WIDE>
+template <int TERMS, int NWV, bool WIDE, bool AMP = false>
 __global__ __launch_bounds__(64 * NWV, 2) void headcom_bwd_w_mask_kernel(
     const float* __restrict__ feat, const unsigned* __restrict__ mask, const float* __restrict__ g,
     float* __restrict__ pw /* (nslab, Cout, Cin) */, float* __restrict__ pb /* (nslab, Cout) */, int N, long long V,
@@ -1095,7 +1099,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void headcom_bwd_w_mask_kernel(
 #pragma unroll
           for (int t = 0; t < TERMS; ++t)
             b[t] = *reinterpret_cast<const bf16x8*>(sFT + t * (64 * 128) + swz(32 * ct + li, 4 * vb + 2 * s2 + lh));
-          dw[ct] = mfma_split<TERMS>(a, b, dw[ct]);
+          dw[ct] = mfma_split<TERMS, AMP>(a, b, dw[ct]);
         }
       }
     }
@@ -1133,7 +1137,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void headcom_bwd_w_mask_kernel(
 // the gradient coefficient is fma(B[k], cx, A[k]) with A[k] = (g0 + gz cz + gy cy) S_dh, the lane's bit of the word
 // (v_bfe_i32: 0 / ~0) masks it -- one broadcast ds_read_b128 and three VALU per element.  The mask words are fetched
 // with the filter block, one block ahead (registers), like the filter fragments themselves.
-template <int TERMS, bool WIDE>
+template <int TERMS, bool WIDE, bool AMP = false>
 __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_mask_kernel(
     const float* __restrict__ feat, const __bf16* __restrict__ wt, const unsigned* __restrict__ mask,
     const float* __restrict__ g, float* __restrict__ dfeat, long long V, int Cin, int Cout, int CoutP, Dims d,
@@ -1237,7 +1241,7 @@ __global__ __launch_bounds__(BF_TPB, 2) void headcom_bwd_feat_mask_kernel(
 #pragma unroll
           for (int t = 0; t < TERMS; ++t)
             a[t] = *reinterpret_cast<const bf16x8*>(sWt + t * (64 * 128) + swz(32 * mt + li, 4 * m + 2 * s2 + lh));
-          acc2[mt] = mfma_split<TERMS>(a, b, acc2[mt]);
+          acc2[mt] = mfma_split<TERMS, AMP>(a, b, acc2[mt]);
         }
       }
     }
@@ -1464,8 +1468,11 @@ static int head_fwd_bf(const float* feat, const float* w, const float* bias, flo
   const size_t lds = 2 * ((size_t)TERMS * FVT * 128 + FVT * sizeof(float4));   // double buffered
   const bool rows = head_rows_ok(D, H, W);
   if (mask && !rows) return -22;             // kmh_headcom_mask_words said 0 for this geometry
-  auto kern = p.nwv == 16 ? (rows ? headcom_fwd_bf_kernel<TERMS, true, 16> : headcom_fwd_bf_kernel<TERMS, false, 16>)
-                          : (rows ? headcom_fwd_bf_kernel<TERMS, true, 4> : headcom_fwd_bf_kernel<TERMS, false, 4>);
+  const bool amp = TERMS == 2 && kmh_amp_enabled();      // use_amp: one product (the kernels that keep the sign mask)
+  auto kern = p.nwv == 16 ? (rows ? (amp ? headcom_fwd_bf_kernel<TERMS, true, 16, true> : headcom_fwd_bf_kernel<TERMS, true, 16>)
+                                  : headcom_fwd_bf_kernel<TERMS, false, 16>)
+                          : (rows ? (amp ? headcom_fwd_bf_kernel<TERMS, true, 4, true> : headcom_fwd_bf_kernel<TERMS, true, 4>)
+                                  : headcom_fwd_bf_kernel<TERMS, false, 4>);
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   kern<<<dim3(p.nslab_f * p.ngroups, N), 64 * p.nwv, lds, s>>>(feat, (const __bf16*)img, bias, partial, V, Cin, Cout, p.CoutP, d,
@@ -1511,7 +1518,9 @@ static int head_bwd_bf(const float* dpts, const float* dpower, const float* feat
     const __bf16* wt = wkp + (size_t)T * pl.CoutP * 64;
     if (dfeat && mask) {
       const size_t lds = 2 * ((size_t)T * 64 * 128 + 8 * WBLK * 16);
-      auto kern = Cin > 32 ? headcom_bwd_feat_mask_kernel<T, true> : headcom_bwd_feat_mask_kernel<T, false>;
+      const bool amp = T == 2 && kmh_amp_enabled();
+      auto kern = Cin > 32 ? (amp ? headcom_bwd_feat_mask_kernel<T, true, true> : headcom_bwd_feat_mask_kernel<T, true>)
+                           : (amp ? headcom_bwd_feat_mask_kernel<T, false, true> : headcom_bwd_feat_mask_kernel<T, false>);
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
       kern<<<dim3(ceil_div(V, 256), N), BF_TPB, lds, s>>>(
@@ -1528,8 +1537,11 @@ static int head_bwd_bf(const float* dpts, const float* dpower, const float* feat
     }
     if (dw && mask) {
       const size_t lds = 2 * ((size_t)T * 64 * 128);                               // double buffered
-      auto kern = pl.nwv_w == 8 ? (Cin > 32 ? headcom_bwd_w_mask_kernel<T, 8, true> : headcom_bwd_w_mask_kernel<T, 8, false>)
-                                : (Cin > 32 ? headcom_bwd_w_mask_kernel<T, 4, true> : headcom_bwd_w_mask_kernel<T, 4, false>);
+      const bool amp = T == 2 && kmh_amp_enabled();
+      auto kern = pl.nwv_w == 8 ? (Cin > 32 ? (amp ? headcom_bwd_w_mask_kernel<T, 8, true, true> : headcom_bwd_w_mask_kernel<T, 8, true>)
+                                            : (amp ? headcom_bwd_w_mask_kernel<T, 8, false, true> : headcom_bwd_w_mask_kernel<T, 8, false>))
+                                : (Cin > 32 ? (amp ? headcom_bwd_w_mask_kernel<T, 4, true, true> : headcom_bwd_w_mask_kernel<T, 4, true>)
+                                            : (amp ? headcom_bwd_w_mask_kernel<T, 4, false, true> : headcom_bwd_w_mask_kernel<T, 4, false>));
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
       kern<<<dim3(pl.nslab_w * pl.ngroups_w), 64 * pl.nwv_w, lds, s>>>(feat, mask, g, pw, pb, N, V, Cin, Cout, pl.CoutP, d,
