@@ -1065,10 +1065,9 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   typedef float kmh_f4 __attribute__((ext_vector_type(4)));      // (a native vector: the asm's "=v" operand)
   // DEEP (round 5, the 32-wide tile without a pre-split operand; KMH_S_DEEP=0: the A/B arm): its 24 MFMAs per step (768 cycles)
   // do not cover an HBM round trip, and a `vmcnt(0)` at every step head made every raw load issued in step s a wait at step
-  // s + 1 (conversion steps 1200 cycles against 910 without a conversion).  As for SPLIT, the B ring holds a whole stage and
-  // fragments are requested 7 steps ahead, so only steps 0 and 7 drain; the raw voxels (compiler-visible loads: the compiler's
-  // own counted waits see only them, i.e. two asm B loads per step fewer than are in flight) are requested THREE steps before
-  // their conversion instead of one.
+  // s + 1 (conversion steps 1200 cycles against 910 without a conversion).  As for SPLIT, the B ring holds a whole stage (in
+  // AGPRs) and fragments are requested 7 steps ahead; the raw voxels are requested THREE steps before their conversion instead
+  // of one.  (First with two drains per stage and compiler-visible raw loads: - 1-2 %; then with the counted waits below.)
   constexpr bool DEEP = (NT == 1) && !ZP && !SPLIT && (KMH_S_DEEP != 0);
   // CW (round 5, every kernel that converts its operand): COUNTED waits.  Loads return in issue order, so `vmcnt(K)` with K =
   // the number of loads issued after the one a step needs says exactly "that one has landed" -- and leaves the younger ones in
@@ -1158,10 +1157,9 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   };
   // B fragments straight from L2 through a two-slot register ring that runs THROUGH the stage boundaries: the fragments of step
   // s + 1 are requested at the HEAD of step s (into the slot step s - 1 has just finished issuing from), so they have a whole
-  // step -- ~1.5k cycles, several L2 round trips -- to land, and every step opens with a plain `s_waitcnt vmcnt(0)`: no counted
-  // waits.  (Counted waits -- vmcnt(number of younger loads), the scheme of conv3_fwd_g_kernel -- gave run-to-run different
-  // results here in the steps that carry no other drain, with strict counts too; the root cause was not found, the full drain
-  // costs nothing once the loads are issued a step ahead.)
+  // step -- ~1.5k cycles, several L2 round trips -- to land.  Without CW (KMH_S_CW=0, round 4) every step opens with a plain
+  // `s_waitcnt vmcnt(0)`; round 4's counted waits gave run-to-run different results here -- the compiler was moving in-flight
+  // destinations (see CW above and b_issue below), which the tied waits and the ISA audit now exclude.
   // SPLIT: the ring holds a whole stage's fragments (one slot per step) and the fragments of step s + BA are requested in step
   // s, so that the wave drains its memory queue only at the head of every BA-th step: the LDS-DMA pieces of the next stage's
   // halo, issued in the steps right after a drain, then have BA - SP_PS + 1 or more steps (thousands of cycles) to come in
