@@ -916,6 +916,9 @@ static_assert(GPL <= S_PLANE && GTZ == 4 && GTY == S_MR, "wave = plane, 8 rows")
 #ifndef KMH_S_DEEP
 #define KMH_S_DEEP 1
 #endif
+#ifndef KMH_S_POOLZ            // 1 = the pooling variant's waves own both planes of a pair (0: a plane each + LDS exchange, the A/B arm)
+#define KMH_S_POOLZ 1
+#endif
 #ifndef KMH_S_CW               // 1 = hand-counted waits in the kernels that convert their operand (0: full drains, the A/B arm)
 #define KMH_S_CW 1
 #endif
@@ -1012,8 +1015,13 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   const float sA = ascale ? ascale[0] : 1.f;
   const float desc = (ascale ? ascale[1] : 1.f) * (wscale ? wscale[1] : 1.f);
   const int nchunk = Cin / KC;
-  const int wz = ZP ? 2 * (wv >> 1) : wv, wy = ZP ? (wv & 1) * MR : 0;      // first output plane / row of the wave
+  // PZ (the pooling variant, round 5): a wave owns rows 4 (wv & 1) .. + 3 of BOTH planes of a plane pair (accumulator rows 0-3 /
+  // 4-7) instead of 8 rows of one plane, so the 2 x 2 x 2 pooling window -- x: a register pair, y: two rows, z: rows m / m + 4 --
+  // lies inside ONE wave: no exchange through LDS, no idle odd-plane waves, every wave transposes and stores 16 values per lane
+  constexpr bool PZ = POOL && (KMH_S_POOLZ != 0);
+  const int wz = (ZP || PZ) ? 2 * (wv >> 1) : wv, wy = ZP ? (wv & 1) * MR : (PZ ? (wv & 1) * (MR / 2) : 0);      // first output plane / row of the wave
   const int vrow = (wz * GHY + wy) * HX + li;
+  auto arow = [](int m) -> int { return PZ ? (m & 3) * HX + (m >> 2) * (GHY * HX) : m * HX; };      // A-image offset of accumulator row m
   const long long vox = (long long)D * H * W;
   const long long plane = SPLIT ? (vox + 1) * KC : vox * KC;      // floats per (sample, chunk) plane of a channel-blocked input
   const long long chunk_stride = (in_blocked || SPLIT) ? plane : KC;
@@ -1292,7 +1300,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
-          for (int q = 0; q < TERMS; ++q) a[0][m][q] = sIn[q * S_PLANE + ab + m * HX];
+          for (int q = 0; q < TERMS; ++q) a[0][m][q] = sIn[q * S_PLANE + ab + arow(m)];
       }
 #pragma unroll
       for (int s = 0; s < NST; ++s) {
@@ -1333,14 +1341,14 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
 #pragma unroll
           for (int m = 0; m < MR; ++m)
 #pragma unroll
-            for (int q = 0; q < TERMS; ++q) a[(s + 1) & 1][m][q] = sIn[q * S_PLANE + ab + m * HX];
+            for (int q = 0; q < TERMS; ++q) a[(s + 1) & 1][m][q] = sIn[q * S_PLANE + ab + arow(m)];
         }
         if (!KMH_S_ADB && s > 0) {                          // single set: read right here, the compiler places the reads
           const int ab = vr + a_offset(s);
 #pragma unroll
           for (int m = 0; m < MR; ++m)
 #pragma unroll
-            for (int q = 0; q < TERMS; ++q) a[0][m][q] = sIn[q * S_PLANE + ab + m * HX];
+            for (int q = 0; q < TERMS; ++q) a[0][m][q] = sIn[q * S_PLANE + ab + arow(m)];
         }
         // the next stage's voxel s - 2 (requested in the last step)
         if (!SPLIT && s >= 1 + CD && s < 9 + CD) convert1(nch, cv_next, pb ^ 1, s - 1 - CD, rawq[(s - 1 - CD) % RQ][0], rawq[(s - 1 - CD) % RQ][1]);
@@ -1449,6 +1457,44 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
         }
       }
       stamp();
+      if constexpr (PZ) {
+        // z children = rows m / m + 4 of THIS wave: pooled rows p = 0, 1 of the lower plane meet p + 2 of the upper one.  Then
+        // the wave's pooled tile (2 rows x 16 columns x 32 channels) is transposed through its own 5 KB so that a lane stores 4
+        // channels of one pooled voxel (16 bytes; a wave instruction = 8 voxels = 1 KB of contiguous output).
+        float* tv = reinterpret_cast<float*>(sEp) + wv * (32 * 32 + 32 * 8);                                // [32 voxels][32]
+        unsigned char* tc = reinterpret_cast<unsigned char*>(tv + 32 * 32);                                 // [32 voxels][32] bytes
+#pragma unroll
+        for (int p = 0; p < MR / 4; ++p) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            float o;
+            unsigned c;
+            pick(pvv[p][q], pvv[p + MR / 4][q], (pcc[p] >> (4 * q)) & 15u, ((pcc[p + MR / 4] >> (4 * q)) & 15u) + 4u, o, c);
+            const int X = (q & 1) + 4 * (q >> 1) + 2 * lh;
+            tv[(p * 16 + X) * 32 + li] = o;
+            tc[(p * 16 + X) * 32 + li] = (unsigned char)c;
+          }
+        }
+        // (the wave's own LDS writes are ordered before its reads)
+        stamp();
+        const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1;
+        const int oz = (z0 + wz) >> 1;
+        const int jx = lane >> 3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int vi = jx + 8 * k, pr = vi >> 4, X = vi & 15;
+          const float4 o4 = *reinterpret_cast<const float4*>(tv + vi * 32 + col);
+          const unsigned cw = *reinterpret_cast<const unsigned*>(tc + vi * 32 + col);
+          const int oy = ((y0 + wy) >> 1) + pr, ox = (x0 >> 1) + X;
+          if (oz < Do && oy < Ho && ox < Wo && co_ok) {
+            const long long e = ((((long long)n * Do + oz) * Ho + oy) * Wo + ox) * Cout + co;
+            *reinterpret_cast<float4*>(y + e) = o4;
+            pool_arg[e >> 2] = cw;
+            st1[0] += o4.x; st2[0] += o4.x * o4.x; st1[1] += o4.y; st2[1] += o4.y * o4.y;
+            st1[2] += o4.z; st2[2] += o4.z * o4.z; st1[3] += o4.w; st2[3] += o4.w * o4.w;
+          }
+        }
+      } else {
       // z children: waves 1, 3 (odd planes) publish, waves 0, 2 combine.  (Splitting the rest of the epilogue between the two
       // waves of a pair -- each finishing two of the four window rows -- was measured: 4.08 against 3.95-4.08 ms, the selects
       // that deal the halves cost what the idle partner would have saved.)
@@ -1504,6 +1550,7 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
           }
         }
       }
+      }   // !PZ
       };
       if (relu_out) pool_block(std::false_type{});
       else pool_block(std::true_type{});
