@@ -6,6 +6,7 @@ repo snapshot (it is git-ignored, not gpurun-ignored).  No JIT at import time.
 from __future__ import annotations
 
 import hashlib
+import re
 import os
 import shutil
 import subprocess
@@ -20,6 +21,13 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=h
          "-Wno-unused-result", "-ffp-contract=fast"]
 
 
+# Per-file extra flags.  conv_wgrad.hip (= the weight-gradient section of conv_bf.hip as its own translation unit): LLVM's
+# "max-ILP" scheduling strategy -- the wave-specialised weight-gradient kernels (several waves per SIMD, no explicit scheduling
+# groups) run 2-4 % faster with it (profiles/r5z_llvm_sched_strategy_max_ilp.txt).  NOT for conv_bf.hip itself: under max-ILP
+# hipcc spills an in-flight destination of conv3_fwd_g_kernel<2>'s inline-asm loads (tools/scan_asm_inflight.py finds it).
+FILE_FLAGS = {"conv_wgrad.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -28,9 +36,15 @@ def _hipcc() -> str:
 
 
 def _digest(path: str) -> str:
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(FILE_FLAGS.items()))).encode())
     with open(path, "rb") as f:
-        h.update(f.read())
+        text = f.read()
+    h.update(text)
+    for inc in re.findall(rb'^#include "([^"]+)"', text, re.M):      # local includes (common.h; conv_wgrad.hip includes conv_bf.hip)
+        q = os.path.join(CSRC, inc.decode())
+        if os.path.exists(q):
+            with open(q, "rb") as f:
+                h.update(f.read())
     with open(os.path.join(CSRC, "common.h"), "rb") as f:
         h.update(f.read())
     return h.hexdigest()
@@ -52,7 +66,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         dig = _digest(src)
         fresh = os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig
         if force or not fresh:
-            cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+            cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)

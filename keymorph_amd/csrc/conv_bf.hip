@@ -34,6 +34,17 @@ namespace {
 
 typedef kmh_f32x16 f32x16;
 typedef kmh_bf16x8 bf16x8;     // 8 x 16-bit fragment (bf16 or fp16 bits; see common.h for the split arithmetic)
+}  // namespace (the typedefs every part of this file uses)
+
+// Two translation units share this file: csrc/conv_wgrad.hip defines KMH_TU_WGRAD and compiles ONLY the weight-gradient section
+// (with LLVM's max-ILP scheduling strategy, keymorph_amd/build.py: its wave-specialised kernels run 2-4 % faster with it),
+// this file compiles everything else with the default strategy -- under max-ILP hipcc spills an in-flight destination of the
+// inline-asm loads of conv3_fwd_g_kernel<2> right behind its load (found by tools/scan_asm_inflight.py).
+#ifndef KMH_TU_WGRAD
+#define KMH_TU_WGRAD 0
+#endif
+#if !KMH_TU_WGRAD
+namespace {
 
 constexpr int TX = 32, TZ = 2;
 constexpr int HX = TX + 2, HZ = TZ + 2;
@@ -2982,6 +2993,8 @@ KMH_API int kmh_conv3d_fwd_bf(const float* x, const float* scale, const float* s
 #undef KMH_BF_CALL
 }
 
+#endif   // !KMH_TU_WGRAD
+#if KMH_TU_WGRAD
 // =============================================================================================
 // Split-bf16 weight gradient: dW[tap][ci][co] = sum_v xn[v + tap][ci] * dz[v][co].
 // K of the MFMA = 16 consecutive voxels of one brick row, so BOTH operands need, per lane, 8 consecutive
@@ -3915,6 +3928,8 @@ KMH_API int kmh_conv3d_wgrad_bf(const float* x, const float* scale, const float*
   return KMH_LAUNCH_CHECK();
 }
 
+#endif   // KMH_TU_WGRAD
+#if !KMH_TU_WGRAD
 // First-layer fold (Cin = 1, GroupNorm over the single input channel): from the raw correlations of ONE sample
 //   rs (Cout, 2, 27): rs[co][0][tap] = R = sum_v x[v+tap] dz[v][co],  rs[co][1][tap] = S = sum_v [inside] dz[v][co]
 // produce  dw (+)= scale*R + shift*S   (the gradient wrt the filter applied to the NORMALISED input) and
@@ -3954,3 +3969,5 @@ KMH_API int kmh_conv3d_first_layer_fold(const void* rs, int rs_f64, const float*
     first_layer_fold_kernel<float><<<1, 256, 0, (hipStream_t)stream>>>((const float*)rs, w, scale_n, shift_n, Cout, dw, ab_n, accumulate);
   return KMH_LAUNCH_CHECK();
 }
+
+#endif   // !KMH_TU_WGRAD
