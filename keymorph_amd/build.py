@@ -25,7 +25,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=h
 # "max-ILP" scheduling strategy -- the wave-specialised weight-gradient kernels (several waves per SIMD, no explicit scheduling
 # groups) run 2-4 % faster with it (profiles/r5z_llvm_sched_strategy_max_ilp.txt).  NOT for conv_bf.hip itself: under max-ILP
 # hipcc spills an in-flight destination of conv3_fwd_g_kernel<2>'s inline-asm loads (tools/scan_asm_inflight.py finds it).
-FILE_FLAGS = {"conv_wgrad.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# norm.hip: its streaming kernels keep more loads in flight under max-ILP (kmh_maxpool3d_bwd_lazy -25 %, kmh_maxpool3d_bwd_split
+# -7 %, GroupNorm kernels unchanged); headcom.hip, grids.hip and the fused decoder kernels get SLOWER with it (+18 % / +4 % / +5 %)
+# and keep the default (profiles/r5z_llvm_sched_strategy_max_ilp.txt).
+_MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+FILE_FLAGS = {"conv_wgrad.hip": _MAX_ILP, "norm.hip": _MAX_ILP}
 
 
 def _hipcc() -> str:
