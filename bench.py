@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--also-f32", type=int, default=3,
                     help="N > 0: also time N steps with the exact fp32-MFMA convolutions (v_mfma_f32_32x32x2_f32) and "
                          "report them as f32_mfma_* next to the f16x3 headline (N = 1 rank only)")
+    ap.add_argument("--first-block-exact", type=int, default=3,
+                    help="N > 0: also time N steps with the first encoder block's 32 -> 16 data gradient on bf16x6 (24 bits at "
+                         "every magnitude; backbone_ops.set_first_block_dgrad) -> first_block_exact_ms_per_step: the price of "
+                         "the option DESIGN section 4 describes; never the headline")
     ap.add_argument("--amp", type=int, default=3,
                     help="N > 0: also time N steps with KeyMorph(use_amp=True) -- the one-product fp16 backbone "
                          "(keymorph/model.py:176-191) -> amp_pairs_per_s, amp_roofline against 2.5 PFLOP/s; never the headline")
@@ -165,21 +169,23 @@ def synthetic_segmentation(img, classes=14):
 
 
 def pmc_traffic(prefix):
-    """HBM bytes per launch of the kernels whose name starts with `prefix`, from the newest committed
-    rocprofv3 --pmc summary under profiles/ (FETCH_SIZE and WRITE_SIZE are collected in separate passes of
+    """HBM bytes per launch of the kernels whose name starts with `prefix`, from the committed rocprofv3 --pmc summary
+    that profiles/LATEST declares to be HEAD's (FETCH_SIZE and WRITE_SIZE are collected in separate passes of
     this same command and corrected as MI355X_MICROARCH.md prescribes: 2 x FETCH_SIZE + WRITE_SIZE; see
     tools/pmc_traffic.py).  Counters cannot be read from inside the timed run, so this is the profiled value
     of the same workload, or None when no summary is present."""
-    import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_hbm_traffic.json")))
-    files = [f for f in files if "before" not in f]
-    if not files:
-        return None, None
-    # a traffic summary older than the newest kernel-trace summary describes another kernel mix: refuse it
-    traces = sorted(glob.glob(os.path.join(os.path.dirname(files[-1]), "*_kernel_trace_stats.md")))
-    tag = lambda f: os.path.basename(f).split("_")[0]      # noqa: E731   "r2c" < "r2d" < "r10a" is not needed: < 10 rounds
-    if traces and tag(files[-1]) < tag(traces[-1]):
-        return None, f"stale ({os.path.basename(files[-1])} is older than {os.path.basename(traces[-1])})"
+    # WHICH summary: profiles/LATEST names the tag of the profile set collected at (or last before) HEAD -- written by the
+    # person who copies a set from gpurun_out/ into profiles/ (tools/profile_round.sh prints the line).  Not the file name
+    # (tags are labels, "r5zz" sorts after "r5last" and is older) and not the mtime (a checkout gives every file the same).
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    try:
+        tag = open(os.path.join(pdir, "LATEST")).read().split()[0]
+    except (OSError, IndexError):
+        return None, "profiles/LATEST missing: no profile set is declared to be HEAD's"
+    f = os.path.join(pdir, f"{tag}_pmc_hbm_traffic.json")
+    if not os.path.exists(f):
+        return None, f"profiles/LATEST names {tag}, which has no {tag}_pmc_hbm_traffic.json"
+    files = [f]
     d = json.load(open(files[-1]))
     n = sum(v["launches"] for k, v in d.items() if k.startswith(prefix))
     if not n:
@@ -347,6 +353,37 @@ def rccl_transport_summary(path):
     return {"via": dict(via), "lines": notes}
 
 
+XGMI_LINK_GBPS = 153.0          # MI355X_MICROARCH.md: 7 point-to-point xGMI links per GPU, ~153 GB/s each
+
+
+def allreduce_expectation(nbytes, world, measured_ms):
+    """What the step's one exchange should cost over xGMI, next to what it did: a ring all-reduce moves 2 (n-1)/n of the bucket
+    through every rank's slowest link (xGMI is point-to-point: one ring is bound by ONE ~153 GB/s link; RCCL's several rings /
+    trees over the 7 links can approach 7x that), plus ~2 (n-1) hop latencies of a few microseconds.  A measured time far above
+    `ring_one_link_ms` means the exchange is NOT on xGMI (see rccl_transport) or the bucket is being split."""
+    if world <= 1:
+        return None
+    moved = 2.0 * (world - 1) / world * nbytes
+    one = 1e3 * moved / (XGMI_LINK_GBPS * 1e9)
+    return {"ring_one_link_ms": one, "all_links_ms": one / min(7, max(world - 1, 1)), "bytes_per_rank_on_the_wire": moved,
+            "link_gb_s": XGMI_LINK_GBPS, "measured_over_one_link": (measured_ms / one) if (measured_ms and one) else None}
+
+
+def check_rccl_transport(summary, backend):
+    """RCCL must carry the gradient bucket over peer-to-peer device memory (xGMI).  Channels `via SHM` (host memory bounce) or
+    `via NET/...` (sockets / IB) on a single node mean a misconfigured box (IPC disabled, HSA_ENABLE_IPC_MODE_LEGACY set wrong,
+    P2P off): the scaling numbers of such a run are not MI355X numbers, so the run fails instead of reporting them.
+    KEYMORPH_BENCH_ALLOW_HOST_TRANSPORT=1 reports them anyway (flagged)."""
+    if backend != "nccl" or not isinstance(summary, dict):
+        return None
+    bad = {k: v for k, v in (summary.get("via") or {}).items() if k.upper().startswith(("SHM", "NET"))}
+    if bad and not os.environ.get("KEYMORPH_BENCH_ALLOW_HOST_TRANSPORT"):
+        raise SystemExit(f"bench.py: RCCL connected channels through host memory / the network ({bad}; all: {summary.get('via')}) "
+                         "instead of peer-to-peer xGMI -- refusing to report multi-GPU numbers from this box "
+                         "(KEYMORPH_BENCH_ALLOW_HOST_TRANSPORT=1 overrides)")
+    return {"host_or_network_channels": bad} if bad else {"host_or_network_channels": {}}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -472,6 +509,19 @@ def main():
         extra.update({"f32_mfma_ms_per_step": 1000 * dt_f, "f32_mfma_pairs_per_s": a.pairs_per_gpu * world / dt_f,
                       "f32_mfma_note": f"same step with KEYMORPH_HIP_CONV=f32 (v_mfma_f32_32x32x2_f32, no operand "
                                        f"splitting), {a.also_f32} timed step(s)"})
+    if a.first_block_exact > 0 and a.conv == "f16x3":
+        backbone_ops.set_first_block_dgrad("bf16x6")
+        n0 = backbone_ops.FIRST_BLOCK_STATS["exact_dgrads"]
+        timed(1)
+        dt_x, loss_x = timed(a.first_block_exact)
+        backbone_ops.set_first_block_dgrad("")
+        extra.update({"first_block_exact_ms_per_step": 1000 * dt_x, "first_block_exact_pairs_per_s": a.pairs_per_gpu * world / dt_x,
+                      "first_block_exact_loss": loss_x,
+                      "first_block_exact_launches_per_step": (backbone_ops.FIRST_BLOCK_STATS["exact_dgrads"] - n0) // (a.first_block_exact + 1),
+                      "first_block_exact_note": "same step with KEYMORPH_FIRST_BLOCK_DGRAD=bf16x6: the 32 -> 16 data gradient of "
+                                                "the first encoder block (256^3) with three bf16 terms / six products on the "
+                                                "generic kernel instead of the pre-split fp16 hi/lo operand; what it buys: "
+                                                "tests/test_fullsize_gpu.py::test_first_block_dgrad_selector_vs_fp64_oracle_128"})
     if a.amp > 0 and a.conv == "f16x3":      # use_amp=True: the one-product fp16 backbone, in the same driver run
         model.use_amp = True
         timed(1)
@@ -483,7 +533,6 @@ def main():
         _lib.profiler.enabled = False
         _lib.profiler.reset()
         model.use_amp = False
-        backbone_ops.set_amp(False)
         ca = {"ms": 0.0, "flops": 0.0}
         for nm in ("kmh_conv3d_fwd_bf", "kmh_conv3d_fwd_bf_pool"):
             for k in ca:
@@ -723,6 +772,10 @@ def main():
         total_ms = sum(v["ms"] for v in prof.values())
         gs = prof.get("kmh_warp_mse_fwd_grad", prof.get("kmh_warp_mse_fwd", prof.get("kmh_grid_sample3d_fwd", {"ms": 0, "bytes": 0})))
         gsb = prof.get("kmh_grid_sample3d_bwd_grid", {"ms": 0, "bytes": 0})
+        backend = torch.distributed.get_backend() if world > 1 else None
+        transport = (rccl_transport_summary(rccl_log) if (rccl_log and world > 1 and backend == "nccl") else
+                     ({"backend": backend} if world > 1 else None))
+        transport_check = check_rccl_transport(transport, backend)      # exits loudly on SHM / NET channels
         out = {
             "metric": "volume-pairs/sec (fwd+bwd) at 256^3, 512 kp, TPS",
             "value": a.pairs_per_gpu * world * a.steps / dt,
@@ -753,11 +806,11 @@ def main():
                                          if all(p == p for p, _ in rank_sensors) else None),
                 "rank_sclk_mhz_min_max": ([min(c for _, c in rank_sensors), max(c for _, c in rank_sensors)]
                                           if all(c == c for _, c in rank_sensors) else None),
-                "rccl_transport": (rccl_transport_summary(rccl_log)
-                                   if (rccl_log and world > 1 and torch.distributed.get_backend() == "nccl") else
-                                   ({"backend": torch.distributed.get_backend()} if world > 1 else None)),
+                "rccl_transport": transport,
+                "rccl_transport_check": transport_check,
                 "allreduce_ms_per_step": allreduce_ms,
                 "allreduce_bytes": 4 * flat.numel,
+                "allreduce_expected": allreduce_expectation(4 * flat.numel, world, allreduce_ms),
                 "pair_seeds_rank0": [100 * rank + i for i in range(a.pairs_per_gpu)],
                 "pair_seed_rule": "rank r owns pairs 100 r + i, i < pairs-per-gpu (synthetic.make_pair seeds)",
                 "parity": "keypoints / grid / warped volume / MSE / Dice within 1e-4 of the reference arithmetic wherever the "

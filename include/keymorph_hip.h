@@ -203,12 +203,12 @@ int kmh_conv3d_fwd_bf(const float* x, const float* scale, const float* shift, co
  * 2: conv3_fwd_g_kernel whenever its preconditions hold (parity tests on small / ragged volumes).  Returns the
  * previous mode, -22 for a bad argument. */
 int kmh_conv3d_fwd_bf_set_dispatch(int mode);
-/* use_amp (keymorph/model.py:176-191 autocasts the keypoint extractor to fp16): on = 1 makes the split-operand kernels of the
- * 27-tap forward / data gradient (one-wave kernels), the wave-specialised weight gradient and the fused decoder operator
- * multiply only the fp16 hi terms -- fp16 inputs, fp32 accumulation, one MFMA per product block instead of three (terms = 2
- * calls only; packing, scales and layouts are unchanged).  Process-wide, KEYMORPH_AMP sets the initial value; returns the
- * previous setting. */
-int kmh_conv_set_amp(int on);
+/* use_amp (keymorph/model.py:176-191 autocasts the keypoint extractor to fp16) is PER CALL: every launching entry point below
+ * that takes `terms` -- kmh_conv3d_fwd_bf, kmh_conv3d_fwd_bf_pool, kmh_conv3d_wgrad_bf, kmh_conv3d_up2_fwd, kmh_conv3d_up2_dgrad,
+ * kmh_up2_wgrad_gemm, kmh_up2_wgrad_fold, kmh_headcom_fwd_bf, kmh_headcom_bwd_bf -- accepts terms == 1 = "the fp16 kernels of
+ * terms == 2 with only the hi x hi product": fp16 inputs (11 significant bits), fp32 accumulation, one MFMA per product block
+ * instead of three.  Packing, scales, layouts, workspaces and the *_ok / *_bytes queries are those of terms == 2 (pass 2
+ * there).  There is no process-wide switch: the caller that ran a forward with terms == 1 passes 1 to its backward calls. */
 /* in_blocked of kmh_conv3d_fwd_bf: 0 = x is (N,D,H,W,Cin); 1 = channel-blocked (N,Cin/8,D,H,W,8) fp32; 2 = PRE-SPLIT
  * channel-blocked: (N, Cin/8, D*H*W + 1) records of 32 bytes, the 8 fp16 "hi" then the 8 fp16 "lo" terms of fmaf(value, S, 0)
  * with S = ascale[0], record D*H*W of every plane zero -- what kmh_maxpool3d_bwd_split writes; the kernel then copies
@@ -272,7 +272,7 @@ int kmh_up2_wgrad_gemm(const float* A, const float* B, float* C, int N, int V, i
  * (keymorph/unet3d/buildingblocks.py:471-475, :46-78). */
 int kmh_up2_wgrad_fold_ok(int Cl, int Cout, int terms);
 size_t kmh_up2_wgrad_fold_ws_bytes(int N, int Dl, int Hl, int Wl, int Cl, int Cout);
-int kmh_up2_wgrad_fold(const float* xl, const float* dz, float* C, int N, int Dl, int Hl, int Wl, int Cl, int Cout,
+int kmh_up2_wgrad_fold(const float* xl, const float* dz, float* C, int N, int Dl, int Hl, int Wl, int Cl, int Cout, int terms,
                        const float* ascale, const float* dscale, const float* a_scale, const float* a_shift, int dz_blocked,
                        void* ws, void* stream);
 int kmh_conv3d_up2_fwd(const float* xl, const float* scale, const float* shift, int Ctot, int cofs, const void* packed,

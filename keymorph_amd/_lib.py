@@ -67,7 +67,6 @@ PROTOS = {
     "kmh_conv3d_pack_weight_bf": (_i, [_f, _f, _i, _i, _i, _i, _f, _f]),
     "kmh_conv3d_fwd_bf": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f]),
     "kmh_conv3d_fwd_bf_set_dispatch": (_i, [_i]),
-    "kmh_conv_set_amp": (_i, [_i]),
     "kmh_conv3d_fwd_bf_variant": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "kmh_conv3d_fwd_bf_pool_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "kmh_conv3d_fwd_bf_split_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),
@@ -81,7 +80,7 @@ PROTOS = {
     "kmh_up2_wgrad_gemm": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
     "kmh_up2_wgrad_fold_ok": (_i, [_i, _i, _i]),
     "kmh_up2_wgrad_fold_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "kmh_up2_wgrad_fold": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f]),
+    "kmh_up2_wgrad_fold": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f]),
     "kmh_conv3d_up2_pack_bytes": (_sz, [_i, _i, _i]),
     "kmh_conv3d_up2_pack_weight": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f]),
     "kmh_conv3d_up2_fwd": (_i, [_f, _f, _f, _i, _i, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),

@@ -133,8 +133,19 @@ __device__ __forceinline__ kmh_f32x16 mfma16(kmh_bf16x8 a, kmh_bf16x8 b, kmh_f32
 }
 // use_amp (keymorph/model.py:176-191 runs the backbone under fp16 autocast): the ONE-product arithmetic of the split-operand
 // kernels -- operands range-scaled and split exactly as for f16x3, only hi x hi multiplied: fp16 inputs (11 significant bits),
-// fp32 accumulation, a third of the MFMA work.  Process-wide switch (kmh_conv_set_amp); kernels are instantiated with AMP = true.
+// fp32 accumulation, a third of the MFMA work.  PER CALL, no process state: an entry point that takes `terms` accepts
+// terms == 1 = "the fp16 kernels (terms 2), hi x hi only"; it opens a KmhAmpCall, which turns the 1 into 2 for everything below
+// and makes kmh_amp_enabled() true on THIS thread until the entry point returns (launchers pick the AMP = true instances).
 bool kmh_amp_enabled();
+bool kmh_amp_call_begin(int* terms);          // returns the previous per-thread state
+void kmh_amp_call_end(bool prev);
+struct KmhAmpCall {
+  bool prev;
+  explicit KmhAmpCall(int& terms) : prev(kmh_amp_call_begin(&terms)) {}
+  ~KmhAmpCall() { kmh_amp_call_end(prev); }
+  KmhAmpCall(const KmhAmpCall&) = delete;
+  KmhAmpCall& operator=(const KmhAmpCall&) = delete;
+};
 // 8 floats -> TERMS fragments (8 x 16 bit each)
 // two values -> TERMS packed 16-bit pairs (lo half = first value): one packed conversion per term
 template <int TERMS>

@@ -1644,26 +1644,17 @@ __global__ __launch_bounds__(S_TPB, 1) void conv3_fwd_s_kernel(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-static std::atomic<int> g_amp{-1};
 }  // namespace
-bool kmh_amp_enabled() {
-  int v = g_amp.load(std::memory_order_relaxed);
-  if (v < 0) {
-    v = (getenv("KEYMORPH_AMP") && atoi(getenv("KEYMORPH_AMP")) != 0) ? 1 : 0;
-    g_amp.store(v, std::memory_order_relaxed);
-  }
-  return v != 0;
+// use_amp per call (common.h): the state is the calling thread's, set for the duration of ONE entry-point call.
+static thread_local bool t_amp_call = false;
+bool kmh_amp_enabled() { return t_amp_call; }
+bool kmh_amp_call_begin(int* terms) {
+  const bool prev = t_amp_call;
+  t_amp_call = (*terms == 1);
+  if (*terms == 1) *terms = 2;
+  return prev;
 }
-/* use_amp: 1 = the split-operand kernels of the 27-tap forward / data gradient (one-wave kernels), the wave-specialised weight
- * gradient and the fused decoder operator multiply only the hi terms (fp16 inputs, fp32 accumulation: one MFMA per product
- * block instead of three); 0 = f16x3 (default; KEYMORPH_AMP sets the initial value).  Process-wide; returns the previous
- * setting.  The first layer, the head, the aligners, the warp and the losses are unaffected (the reference's autocast,
- * keymorph/model.py:176-191, also leaves everything after the keypoints in fp32). */
-KMH_API int kmh_conv_set_amp(int on) {
-  const int old = kmh_amp_enabled() ? 1 : 0;
-  g_amp.store(on ? 1 : 0, std::memory_order_relaxed);
-  return old;
-}
+void kmh_amp_call_end(bool prev) { t_amp_call = prev; }
 namespace {
 static inline int cout_pad(int Cout) { return Cout > 64 ? (Cout + 127) & ~127 : (Cout + 63) & ~63; }
 static inline bool use_zpair(int Cout) { return Cout <= 16; }
@@ -2502,6 +2493,7 @@ KMH_API size_t kmh_up2_wgrad_gemm_ws_bytes(int N, int V, int Cl, int J) {
 KMH_API int kmh_up2_wgrad_gemm(const float* A, const float* B, float* C, int N, int V, int Cl, int J, int terms,
                                const float* ascale, const float* bscale, const float* a_scale, const float* a_shift,
                                void* ws, void* stream) {
+  KmhAmpCall amp_call(terms);      // terms == 1: the fp16 kernels with hi x hi only (use_amp), for this call
   if ((Cl & 3) || (J & 3) || (terms != 2 && terms != 3) || (terms == 2 && (!ascale || !bscale)) || (!a_scale != !a_shift))
     return -22;
   int ks;
@@ -2555,10 +2547,14 @@ KMH_API int kmh_up2_wgrad_fold_ok(int Cl, int Cout, int terms) {
   return (terms == 2 && Cl > 0 && (Cl & 3) == 0 && Cout > 0 && (Cout & 7) == 0) ? 1 : 0;
 }
 
-KMH_API size_t kmh_up2_wgrad_fold_ws_bytes(int N, int Dl, int Hl, int Wl, int Cl, int Cout) {
+static inline size_t up2_fold_slab_bytes(int N, int Dl, int Hl, int Wl, int Cl, int Cout) {
   int tps, kt;
   const int ns = up2_fold_slabs(N, Dl, Hl, Wl, Cl, Cout, &tps, &kt);
-  return (size_t)N * ns * Cl * 27 * Cout * sizeof(float);
+  return (((size_t)N * ns * Cl * 27 * Cout * sizeof(float)) + 255) & ~(size_t)255;
+}
+/* the partial slabs + 256 bytes of zeros (the source of window voxels outside the volume; written by every call on its stream) */
+KMH_API size_t kmh_up2_wgrad_fold_ws_bytes(int N, int Dl, int Hl, int Wl, int Cl, int Cout) {
+  return up2_fold_slab_bytes(N, Dl, Hl, Wl, Cl, Cout) + 256;
 }
 
 template <bool AMP, int MODE>
@@ -2576,11 +2572,13 @@ static int launch_up2_fold(dim3 g, hipStream_t s, const float* xl, const float* 
 
 /* C (N, Cl, 27 Cout) = kmh_up2_wgrad_gemm(xl, kmh_up2_boxsum(dz)) without the box-sum tensor: xl (N, Dl, Hl, Wl, Cl) the raw
  * low tensor (a_scale / a_shift: GroupNorm's affine, or both NULL), dz (N, 2Dl, 2Hl, 2Wl, Cout) or channel-blocked
- * (dz_blocked), ascale / dscale = {S, 1/S} range scales of the normalised low tensor and of dz. */
+ * (dz_blocked), ascale / dscale = {S, 1/S} range scales of the normalised low tensor and of dz; terms: 2, or 1 = hi x hi only
+ * (use_amp); ws: kmh_up2_wgrad_fold_ws_bytes, 16-byte aligned. */
 KMH_API int kmh_up2_wgrad_fold(const float* xl, const float* dz, float* C, int N, int Dl, int Hl, int Wl, int Cl, int Cout,
-                               const float* ascale, const float* dscale, const float* a_scale, const float* a_shift,
+                               int terms, const float* ascale, const float* dscale, const float* a_scale, const float* a_shift,
                                int dz_blocked, void* ws, void* stream) {
-  if (!kmh_up2_wgrad_fold_ok(Cl, Cout, 2) || !ascale || !dscale || (!a_scale != !a_shift) || N <= 0 || N > 65535) return -22;
+  KmhAmpCall amp_call(terms);      // terms == 1: hi x hi only (use_amp), for this call
+  if (!ws || ((uintptr_t)ws & 15) || !kmh_up2_wgrad_fold_ok(Cl, Cout, terms) || !ascale || !dscale || (!a_scale != !a_shift) || N <= 0 || N > 65535) return -22;
   int tps, kt;
   const int ns = up2_fold_slabs(N, Dl, Hl, Wl, Cl, Cout, &tps, &kt);
   const int mode = up2_fold_mode(Cl, Cout);
@@ -2588,17 +2586,14 @@ KMH_API int kmh_up2_wgrad_fold(const float* xl, const float* dz, float* C, int N
   hipStream_t s = (hipStream_t)stream;
   dim3 g(nto * ntm * ns, 1, N);
   static const int xcd = getenv("KEYMORPH_UP2_GEMM_NO_XCD") ? 0 : 1;
-  static float* zero16[64] = {nullptr};                     // per device: 256 bytes of zeros, the source of voxels outside the volume
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -22;
-  if (!zero16[dev]) {
-    if (hipMalloc(&zero16[dev], 256) != hipSuccess) return -12;
-    if (hipMemset(zero16[dev], 0, 256) != hipSuccess) return -12;
-  }
+  // 256 bytes of zeros behind the slabs: the LDS-DMA source of window voxels outside the volume.  From the caller's workspace,
+  // zeroed on the caller's stream: no allocation, no host synchronisation, nothing process-wide (stream capture stays legal).
+  const float* zero16 = (const float*)((const char*)ws + up2_fold_slab_bytes(N, Dl, Hl, Wl, Cl, Cout));
+  if (hipMemsetAsync((void*)zero16, 0, 256, s) != hipSuccess) return -12;
   const bool amp = kmh_amp_enabled();
   int rc;
 #define KMH_FOLD(A, M) launch_up2_fold<A, M>(g, s, xl, dz, (float*)ws, Dl, Hl, Wl, Cl, Cout, kt, tps, ntm, nto, ascale, dscale, \
-                                             a_scale, a_shift, dz_blocked, xcd, zero16[dev])
+                                             a_scale, a_shift, dz_blocked, xcd, zero16)
   if (mode == 2) rc = amp ? KMH_FOLD(true, 2) : KMH_FOLD(false, 2);
   else if (mode == 1) rc = amp ? KMH_FOLD(true, 1) : KMH_FOLD(false, 1);
   else rc = amp ? KMH_FOLD(true, 0) : KMH_FOLD(false, 0);
@@ -2638,6 +2633,7 @@ KMH_API size_t kmh_conv3d_up2_dgrad_stats_ws_bytes(int N, int Dl, int Hl, int Wl
 KMH_API int kmh_conv3d_up2_dgrad(const float* dz, const void* packed, float* ds, int N, int Dl, int Hl, int Wl, int Cl,
                                  int Cout, int terms, const float* dscale, const float* wscale, void* stats_ws,
                                  double* stats_out, int in_blocked, void* stream) {
+  KmhAmpCall amp_call(terms);      // terms == 1: the fp16 kernels with hi x hi only (use_amp), for this call
   if ((terms != 2 && terms != 3) || (terms == 2 && (!dscale || !wscale)) || (stats_out && !stats_ws)) return -22;
   if (in_blocked && (Cout & 7)) return -22;               // whole 8-channel chunks
   const int CiP = (Cl + 127) & ~127;
@@ -2683,6 +2679,7 @@ KMH_API int kmh_conv3d_up2_pack_weight(const float* w, void* packed, int Cout, i
 KMH_API int kmh_conv3d_up2_fwd(const float* xl, const float* scale, const float* shift, int Ctot, int cofs,
                                const void* packed, float* y, int N, int Dl, int Hl, int Wl, int Cl, int Cout, int terms,
                                const float* ascale, const float* wscale, void* stream) {
+  KmhAmpCall amp_call(terms);      // terms == 1: the fp16 kernels with hi x hi only (use_amp), for this call
   if ((Cl & 7) || (terms != 2 && terms != 3) || (terms == 2 && (!ascale || !wscale))) return -22;
   if ((long long)Dl * Hl * Wl * Cl >= (1ll << 31)) return -22;
   const int CoutP = cout_pad(Cout);
@@ -2894,6 +2891,7 @@ KMH_API int kmh_conv3d_fwd_bf_pool(const float* x, const float* scale, const flo
                                    unsigned char* arg, int N, int D, int H, int W, int Cin, int Cout, int relu_in,
                                    int terms, const float* ascale, const float* wscale, void* stats_ws, double* stats_out,
                                    int in_blocked, void* stream) {
+  KmhAmpCall amp_call(terms);      // terms == 1: the fp16 kernels with hi x hi only (use_amp), for this call
   if (!kmh_conv3d_fwd_bf_pool_ok(N, D, H, W, Cin, Cout, terms) || !ascale || !wscale || !yp || !arg) return -22;
   if (((uintptr_t)yp & 15) || ((uintptr_t)arg & 3)) return -22;
   // the one-wave kernel's pooling epilogue (KEYMORPH_FWD_S=0 or KEYMORPH_POOL_G=1: the eight-wave kernel's, the A/B arm;
@@ -2932,6 +2930,7 @@ KMH_API int kmh_conv3d_fwd_bf(const float* x, const float* scale, const float* s
                               int Cout, int relu_in, int relu_out, int terms, int rows_per_wave, const float* ascale,
                               const float* wscale, void* stats_ws, double* stats_out, int in_blocked,
                               const float* addend, void* stream) {
+  KmhAmpCall amp_call(terms);      // terms == 1: the fp16 kernels with hi x hi only (use_amp), for this call
   const int CoutP = cout_pad(Cout);
   hipStream_t s = (hipStream_t)stream;
   const bf16x8* wp = (const bf16x8*)packed;
@@ -3887,6 +3886,7 @@ KMH_API int kmh_conv3d_wgrad_bf(const float* x, const float* scale, const float*
                                 int relu_in, int accumulate, int terms, int append_ones, const float* xscale,
                                 const float* dscale, int dz_blocked, const float* w_fold, double* bhat, void* ws,
                                 void* stream) {
+  KmhAmpCall amp_call(terms);      // terms == 1: the fp16 kernels with hi x hi only (use_amp), for this call
   hipStream_t s = (hipStream_t)stream;
   if ((w_fold == nullptr) != (bhat == nullptr)) return -22;
   const WgradBfPlan p = wgrad_bf_plan(N, D, H, W, Cin, Cout, terms);

@@ -1598,6 +1598,7 @@ KMH_API size_t kmh_headcom_mask_words(int N, int D, int H, int W, int Cout) {
 KMH_API int kmh_headcom_fwd_bf(const float* feat, const float* w, const float* bias, float* pts, float* sums, float* sq,
                                float* scales_out, int N, int D, int H, int W, int Cin, int Cout, int terms, unsigned* mask,
                                void* ws, void* stream) {
+  KmhAmpCall amp_call(terms);      // terms == 1: the fp16 kernels with hi x hi only (use_amp), for this call
   if (Cin > 64 || (Cin & 3) || (terms != 2 && terms != 3)) return -22;
   return terms == 3
              ? head_fwd_bf<3>(feat, w, bias, pts, sums, sq, scales_out, N, D, H, W, Cin, Cout, mask, ws, (hipStream_t)stream)
@@ -1607,6 +1608,7 @@ KMH_API int kmh_headcom_bwd_bf(const float* dpts, const float* dpower, const flo
                                const float* sums, float* dfeat, float* dw, float* dbias, int N, int D, int H, int W,
                                int Cin, int Cout, int terms, int mask_dfeat, const float* scales_in,
                                float* dfeat_scale2, const unsigned* mask, void* ws, void* stream) {
+  KmhAmpCall amp_call(terms);      // terms == 1: the fp16 kernels with hi x hi only (use_amp), for this call
   if (Cin > 64 || (Cin & 3) || (terms != 2 && terms != 3)) return -22;
   return terms == 3 ? head_bwd_bf<3>(dpts, dpower, feat, w, bias, sums, dfeat, dw, dbias, N, D, H, W, Cin, Cout,
                                      mask_dfeat, scales_in, dfeat_scale2, mask, ws, (hipStream_t)stream)

@@ -41,9 +41,10 @@ class KeyMorph(nn.Module):
         self.max_train_keypoints = max_train_keypoints
         # use_amp (keymorph/model.py:176-191: the reference runs the keypoint extractor under fp16 autocast): the one-product
         # fp16 arithmetic of the backbone's matrix kernels -- fp16 inputs (11 significant bits), fp32 accumulation and fp32
-        # tensors, a third of the MFMA work -- instead of the fp32-class split-operand default.  The switch is process-wide
-        # (backbone_ops.set_amp) and is set by every call of get_keypoints(), so the backward of a step runs under the
-        # setting of its forward; aligners, warp and losses are fp32 either way, as in the reference.
+        # tensors, a third of the MFMA work -- instead of the fp32-class split-operand default.  Per call, not process-wide:
+        # get_keypoints() runs the backbone inside backbone_ops.amp_scope(self.use_amp), every operator records the setting
+        # of its forward and its backward re-opens it (another model, with another setting, between the two changes nothing);
+        # aligners, warp and losses are fp32 either way, as in the reference.
         self.use_amp = bool(use_amp)
         self.use_checkpoint = use_checkpoint
         self.max_rand_tps_lmbda = max_rand_tps_lmbda
@@ -60,7 +61,11 @@ class KeyMorph(nn.Module):
         """model.py:111-117"""
         if img.is_cuda:
             from . import backbone_ops
-            backbone_ops.set_amp(self.use_amp)
+            with backbone_ops.amp_scope(self.use_amp):
+                return self._get_keypoints(img, return_feat)
+        return self._get_keypoints(img, return_feat)
+
+    def _get_keypoints(self, img, return_feat):
         net = getattr(self.backbone, "module", self.backbone)   # nn.DataParallel wrapper (run.py:390)
         if (not return_feat and self.dim == 3 and hasattr(net, "keypoints_ij")
                 and (net.final_activation is None or net.training)):

@@ -38,13 +38,14 @@ class SingleConv(nn.Module):
         self._dy_premasked = False
 
     def forward(self, x, dy_premasked=None, dy_blocked=False, dx_blocked=False, pool=False, dy_lazy=False,
-                dx_lazy=False):  # x NDHWC
+                dx_lazy=False, dgrad_terms=0):  # x NDHWC
         """dy_premasked overrides the static promise for this call (the fused keypoint head masks its feature gradient);
         dy_blocked / dx_blocked: see DoubleConv.forward; pool: return maxpool2 of the output (B.conv_pool_ok)."""
         return B.single_conv_gcr(x, self.groupnorm.weight, self.groupnorm.bias, self.conv.weight, self._groups,
                                  x_from_relu=not self._first,
                                  dy_premasked=self._dy_premasked if dy_premasked is None else dy_premasked,
-                                 dy_blocked=dy_blocked, dx_blocked=dx_blocked, pool=pool, dy_lazy=dy_lazy, dx_lazy=dx_lazy)
+                                 dy_blocked=dy_blocked, dx_blocked=dx_blocked, pool=pool, dy_lazy=dy_lazy, dx_lazy=dx_lazy,
+                                 dgrad_terms=dgrad_terms)
 
 
 class DoubleConv(nn.Module):
@@ -75,7 +76,8 @@ class DoubleConv(nn.Module):
         lazy = (self.SingleConv1._first and self.SingleConv1._dy_premasked and not blk
                 and B.lazy_first_layer_ok(x, self.SingleConv1.conv.out_channels))
         return self.SingleConv2(self.SingleConv1(x, dy_blocked=blk, dy_lazy=lazy), out_premasked,
-                                dy_blocked=out_dy_blocked, dx_blocked=blk, pool=out_pool, dx_lazy=lazy)
+                                dy_blocked=out_dy_blocked, dx_blocked=blk, pool=out_pool, dx_lazy=lazy,
+                                dgrad_terms=B.first_block_dgrad_terms() if self.SingleConv1._first else 0)
 
 
 class Encoder(nn.Module):

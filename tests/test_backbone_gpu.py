@@ -874,7 +874,7 @@ def test_up2_weight_gradient_with_the_box_sums_formed_inside_the_product(cfg, fo
     outs = []
     for blocked in (0, 1):
         got = torch.full((N, Cl, 27 * Cout), float("nan"), device=DEV)
-        check(lib.kmh_up2_wgrad_fold(_p(xl), _p(dzb if blocked else dz), _p(got), N, ld[0], ld[1], ld[2], Cl, Cout, _p(asc),
+        check(lib.kmh_up2_wgrad_fold(_p(xl), _p(dzb if blocked else dz), _p(got), N, ld[0], ld[1], ld[2], Cl, Cout, 2, _p(asc),
                                      _p(dsc), _p(sc), _p(sh), blocked, _p(ws2), _stream()), "kmh_up2_wgrad_fold")
         assert bool(torch.isfinite(got).all())
         outs.append(got)
@@ -885,7 +885,7 @@ def test_up2_weight_gradient_with_the_box_sums_formed_inside_the_product(cfg, fo
     close(old.double(), ref, 3e-6 * scale, 1e-4)
     close(outs[0], old, 2e-6 * scale, 1e-4)                           # same operand images: only the summation order differs
     again = torch.empty_like(outs[0])
-    check(lib.kmh_up2_wgrad_fold(_p(xl), _p(dz), _p(again), N, ld[0], ld[1], ld[2], Cl, Cout, _p(asc), _p(dsc), _p(sc), _p(sh),
+    check(lib.kmh_up2_wgrad_fold(_p(xl), _p(dz), _p(again), N, ld[0], ld[1], ld[2], Cl, Cout, 2, _p(asc), _p(dsc), _p(sc), _p(sh),
                                  0, _p(ws2), _stream()), "kmh_up2_wgrad_fold")
     assert torch.equal(again, outs[0])                                # deterministic
 

@@ -540,6 +540,45 @@ def test_backbone_backward_vs_fp64_oracle_128():
     assert whole_h <= 5e-4, (whole_h, whole_o)
 
 
+def test_first_block_dgrad_selector_vs_fp64_oracle_128():
+    """Round 6: `KEYMORPH_FIRST_BLOCK_DGRAD=bf16x6` / backbone_ops.set_first_block_dgrad runs the
+    first encoder block's 32 -> 16 data gradient -- the launch behind the first GroupNorm's cancelling sums -- with three bf16
+    terms (24 bits at every magnitude) while everything else stays f16x3.  Same comparison as above: the selector must have
+    taken the launch, every tensor outside the first block is unchanged bit for bit (only that launch differs), the first
+    block's tensors stay inside the default's bar, and the table (default / selector / reference fp32, against fp64) is
+    printed: DESIGN section 4 quotes it as the price / benefit of the option."""
+    from keymorph_amd import backbone_ops as B
+    from tests.oracle_at_size import hip_model, oracle_backbone_fp64
+    if _host_ram_gib() < 48:
+        pytest.skip("needs ~12 GB of host RAM for the fp64 autograd graph at 128^3")
+    S, Kk = 128, 512
+    ref = oracle_backbone_fp64(S, Kk)
+    g64, g32 = ref["grads_fp64"], ref["grads_fp32"]
+    got = {}
+    try:
+        for mode in ("", "bf16x6"):
+            B.set_first_block_dgrad(mode)
+            n0 = B.FIRST_BLOCK_STATS["exact_dgrads"]
+            km = hip_model(ref["sd"], Kk, DEV)
+            pts = km.get_keypoints(ref["x"].to(DEV))
+            torch.autograd.backward([pts], [ref["cot"].to(DEV)])
+            assert (B.FIRST_BLOCK_STATS["exact_dgrads"] - n0) == (1 if mode else 0)
+            got[mode] = {k: p.grad.detach().cpu() for k, p in km.backbone.named_parameters()}
+            del km
+    finally:
+        B.set_first_block_dgrad("")
+    err = lambda g, k: float((g.double() - g64[k].double()).norm() / (g64[k].double().norm() + 1e-300))      # noqa: E731
+    print("first-block data-gradient arithmetic vs fp64 at 128^3 / 512 kp (relative L2):   f16x3   bf16x6-selector   reference fp32")
+    for k in got[""]:
+        if k.startswith("encoders.0."):
+            print(f"   {k:58s} {err(got[''][k], k):.2e}   {err(got['bf16x6'][k], k):.2e}   {err(g32[k], k):.2e}")
+    for k in got[""]:
+        # the selector changes ONE launch: tensors whose gradient does not pass through it are bit-identical
+        if not k.startswith(("encoders.0.basic_module.SingleConv1.", "encoders.0.basic_module.SingleConv2.groupnorm.")):
+            assert torch.equal(got[""][k], got["bf16x6"][k]), k
+        assert err(got["bf16x6"][k], k) <= (8e-3 if k.startswith("encoders.0.") else max(1e-3, 1.25 * err(g32[k], k))), k
+
+
 def test_tps_training_step_vs_oracle_autograd_64_k512():
     """ONE training step with a TPS transform and the production kernel variants that do not need a large volume -- K = 512
     keypoints, so the workgroup-cluster LU and the row-hoisted T = 512 grid evaluators run, forward AND backward -- against
@@ -579,8 +618,9 @@ def test_use_amp_one_product_backbone_vs_oracle_128():
     """use_amp=True (keymorph/model.py:176-191: the reference autocasts the keypoint extractor to fp16): the one-product fp16
     arithmetic of the 27-tap / weight-gradient / decoder kernels -- fp16 inputs, fp32 accumulation, fp32 tensors.  At 128^3 /
     512 keypoints against the fp32 oracle: keypoints <= 2e-3, every gradient finite, whole gradient vector <= 5e-2 relative
-    L2; it is a different arithmetic from the default (results differ) and the default comes back when a use_amp=False model
-    runs (the switch is process-wide, set by every get_keypoints())."""
+    L2; it is a different arithmetic from the default (results differ).  The setting is per call: a model with the OPPOSITE
+    setting run between the forward and the backward changes nothing (the gradient bars below hold for both), and nothing of
+    it is left when get_keypoints() returns."""
     from keymorph_amd import backbone_ops as B
     from tests.oracle_at_size import hip_model, oracle_backbone_fp64
     if _host_ram_gib() < 48:
@@ -588,12 +628,16 @@ def test_use_amp_one_product_backbone_vs_oracle_128():
     S, Kk = 128, 512
     ref = oracle_backbone_fp64(S, Kk)
     out = {}
-    try:
+    other = hip_model(ref["sd"], Kk, DEV)                      # a second model with the OPPOSITE setting, called between the
+    try:                                                       # forward and the backward of the one under test
         for amp in (True, False):
             km = hip_model(ref["sd"], Kk, DEV)
             km.use_amp = amp
             pts = km.get_keypoints(ref["x"].to(DEV))
-            assert B.set_amp(amp) == amp                       # get_keypoints() set the library's switch
+            assert B.amp_enabled() is False                    # the setting ended with get_keypoints()
+            other.use_amp = not amp
+            with torch.no_grad():
+                other.get_keypoints(ref["x"].to(DEV))
             torch.autograd.backward([pts], [ref["cot"].to(DEV)])
             num = den = 0.0
             for k, p in km.backbone.named_parameters():
@@ -603,7 +647,7 @@ def test_use_amp_one_product_backbone_vs_oracle_128():
             out[amp] = (float((pts.detach().cpu() - ref["pts_fp32"]).abs().max()), (num / den) ** 0.5, pts.detach().clone())
             del km
     finally:
-        B.set_amp(False)
+        del other
     print(f"use_amp at 128^3 / 512 kp vs the fp32 oracle: keypoints {out[True][0]:.2e} (default {out[False][0]:.2e}), "
           f"gradient {out[True][1]:.2e} (default {out[False][1]:.2e})")
     assert out[True][0] <= 2e-3 and out[True][1] <= 5e-2, out[True][:2]

@@ -419,3 +419,31 @@ def test_bench_rccl_transport_summary_and_sensor_fallback(tmp_path):
     assert "error" in bench.rccl_transport_summary(str(tmp_path / "absent.log"))
     if not torch.cuda.is_available():
         assert bench.gpu_sensors(0) == (None, None)
+
+
+def test_bench_transport_check_allreduce_expectation_and_profile_manifest(tmp_path, monkeypatch):
+    """Round 6: (i) channels `via SHM` / `via NET` in RCCL's set-up log end a multi-GPU bench run loudly --
+    a single node whose all-reduce bounces through host memory is a misconfigured box, not an MI355X number; (ii) the measured
+    all-reduce is printed next to what 2 (n-1)/n of the bucket costs on one 153 GB/s xGMI link; (iii) the PMC traffic summary
+    is the one profiles/LATEST declares to be HEAD's, not the lexicographically last tag."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    assert bench.check_rccl_transport({"via": {"P2P/IPC": 56}}, "nccl") == {"host_or_network_channels": {}}
+    assert bench.check_rccl_transport({"backend": "gloo"}, "gloo") is None
+    for bad in ({"P2P/IPC": 6, "SHM/direct/direct": 8}, {"NET/Socket/0": 2}):
+        with pytest.raises(SystemExit) as e:
+            bench.check_rccl_transport({"via": bad}, "nccl")
+        assert "xGMI" in str(e.value)
+    monkeypatch.setenv("KEYMORPH_BENCH_ALLOW_HOST_TRANSPORT", "1")
+    assert bench.check_rccl_transport({"via": {"SHM/direct/direct": 8}}, "nccl") == {"host_or_network_channels": {"SHM/direct/direct": 8}}
+    ex = bench.allreduce_expectation(16 * 2 ** 20, 8, 0.5)
+    assert abs(ex["ring_one_link_ms"] - 1e3 * (2 * 7 / 8 * 16 * 2 ** 20) / 153e9) < 1e-9 and ex["all_links_ms"] == ex["ring_one_link_ms"] / 7
+    assert abs(ex["measured_over_one_link"] - 0.5 / ex["ring_one_link_ms"]) < 1e-9 and bench.allreduce_expectation(1, 1, 0.0) is None
+    # the committed manifest names a committed summary with conv3_fwd_* entries
+    mb, src = bench.pmc_traffic("conv3_fwd_")
+    tag = open(os.path.join(root, "profiles", "LATEST")).read().split()[0]
+    assert src == f"{tag}_pmc_hbm_traffic.json" and mb and mb > 1e8, (mb, src)

@@ -13,6 +13,6 @@ for d in sys.argv[1:]:
 for k, v in agg.items():
     if not any(t in k for t in ("conv3", "headcom", "tps", "sample", "warp_dice", "dice_partial", "elementwise", "copy")):
         continue
-    print(k)
+    print(f"{k}   [{len(cnt[k])} dispatches]")
     for c, x in sorted(v.items()):
         print(f"   {c:34s} {x:16.0f}")

@@ -32,3 +32,30 @@ rt.sort(key=lambda e: -e.count)
 print("runtime calls per step (besides kernel launches):")
 for e in rt[:15]:
     print(f"  {e.count / 2:7.1f}/step  {e.cpu_time_total / 2e3:8.3f} ms/step host  {e.key}")
+# ---- round 6: WHO launches the elementwise adds (35 `CUDAFunctor_add` launches per step, 0.93 ms, 6.6 GB) ----
+# one more step with Python stacks; every aten::add / add_ / sum / mul / copy_ with GPU time is attributed to the chain of its
+# CPU parents (the autograd node that ran it: "...: XBackward" = inside that Function's backward, bare "evaluate_function" with an
+# AccumulateGrad / no Python frame = the engine summing two gradients of a tensor that was used twice) and its Python frame.
+if os.environ.get("KMH_WHO", "1") != "0":
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof2:
+        bench.train_step(model, flat, opt, img_f, img_m, "tps_0")
+        torch.cuda.synchronize()
+    import collections
+    who = collections.defaultdict(lambda: [0, 0.0])
+    for e in prof2.events():
+        if not e.name.startswith(("aten::add", "aten::sum", "aten::mul", "aten::copy_", "aten::cat", "aten::clone", "aten::div", "aten::sub")):
+            continue
+        if e.self_device_time_total <= 0:
+            continue
+        chain, p = [], e.cpu_parent
+        while p is not None:
+            if not p.name.startswith("aten::"):
+                chain.append(p.name[:70])
+            p = p.cpu_parent
+        frame = next((s for s in (e.stack or []) if "keymorph_amd" in s or "bench.py" in s), "")
+        key = (e.name, str(e.input_shapes)[:70], " <- ".join(chain[:2]), frame.strip()[-90:])
+        who[key][0] += 1
+        who[key][1] += e.self_device_time_total
+    print("who launches the elementwise / reduction ATen kernels (one step):")
+    for key, (n, us) in sorted(who.items(), key=lambda kv: -kv[1][1])[:40]:
+        print(f"{us / 1e3:8.3f} ms {n:3d}x  {key[0]:14s} {key[1]:70s}\n              parents: {key[2]}\n              frame:   {key[3]}")

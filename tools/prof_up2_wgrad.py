@@ -24,9 +24,9 @@ for (N, ld, Cl, Cout) in ((4, (64, 64, 64), 128, 64), (4, (32, 32, 32), 256, 128
         check(lib.kmh_up2_wgrad_gemm(_p(xl), _p(boxes), _p(old), N, Vl, Cl, 27 * Cout, 2, _p(asc), _p(bsc), _p(sc), _p(sh), _p(ws), _stream()), "gemm")
     dzb = dz.reshape(N, -1, Cout // 8, 8).permute(0, 2, 1, 3).contiguous()
     def b():
-        check(lib.kmh_up2_wgrad_fold(_p(xl), _p(dz), _p(new), N, ld[0], ld[1], ld[2], Cl, Cout, _p(asc), _p(dsc), _p(sc), _p(sh), 0, _p(ws2), _stream()), "fold")
+        check(lib.kmh_up2_wgrad_fold(_p(xl), _p(dz), _p(new), N, ld[0], ld[1], ld[2], Cl, Cout, 2, _p(asc), _p(dsc), _p(sc), _p(sh), 0, _p(ws2), _stream()), "fold")
     def c():
-        check(lib.kmh_up2_wgrad_fold(_p(xl), _p(dzb), _p(new), N, ld[0], ld[1], ld[2], Cl, Cout, _p(asc), _p(dsc), _p(sc), _p(sh), 1, _p(ws2), _stream()), "fold")
+        check(lib.kmh_up2_wgrad_fold(_p(xl), _p(dzb), _p(new), N, ld[0], ld[1], ld[2], Cl, Cout, 2, _p(asc), _p(dsc), _p(sc), _p(sh), 1, _p(ws2), _stream()), "fold")
     def d():
         check(lib.kmh_up2_boxsum(_p(dzb), _p(boxes), N, ld[0], ld[1], ld[2], Cout, 1, _stream()), "boxsum")
         check(lib.kmh_up2_wgrad_gemm(_p(xl), _p(boxes), _p(old), N, Vl, Cl, 27 * Cout, 2, _p(asc), _p(bsc), _p(sc), _p(sh), _p(ws), _stream()), "gemm")
