@@ -66,6 +66,7 @@ PROTOS = {
     "kmh_conv3d_pack_bf_bytes": (_sz, [_i, _i, _i, _i]),
     "kmh_conv3d_pack_weight_bf": (_i, [_f, _f, _i, _i, _i, _i, _f, _f]),
     "kmh_conv3d_fwd_bf": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f]),
+    "kmh_sampler_set_persistent": (_i, [_i]),
     "kmh_conv3d_fwd_bf_set_dispatch": (_i, [_i]),
     "kmh_conv3d_fwd_bf_variant": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "kmh_conv3d_fwd_bf_pool_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),
@@ -193,6 +194,9 @@ class _Proxy:
         return call
 
 
+_DEFAULT_LIBPATH = LIBPATH
+
+
 def load():
     """dlopen the HIP library (idempotent).  Raises if it has not been built."""
     global _lib, LIBPATH
@@ -215,8 +219,14 @@ def load():
     else:  # system ROCm PyTorch build
         C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIBPATH)
+    ab_build = os.path.abspath(LIBPATH) != os.path.abspath(_DEFAULT_LIBPATH)      # another build, named explicitly (A/B timing)
     for name, (res, args) in PROTOS.items():
-        fn = getattr(lib, name)  # AttributeError => ABI mismatch, fail loudly
+        try:
+            fn = getattr(lib, name)  # AttributeError => ABI mismatch, fail loudly ...
+        except AttributeError:
+            if not ab_build:
+                raise
+            continue                 # ... except for an explicitly named A/B build of an older commit: calling the symbol raises
         fn.restype = res
         fn.argtypes = args
     if lib.kmh_abi_version() != 1:

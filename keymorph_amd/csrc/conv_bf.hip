@@ -3013,6 +3013,14 @@ constexpr int XPITCH = 24;                 // elements per halo row (18 used)
 constexpr int XPLANE = 1168;               // bytes per channel plane (24 rows x 48 B = 1152, padded)
 constexpr int DPLANE = 272;                // bytes per cout plane (128 voxels x 2 B = 256, padded)
 constexpr int WV = WX * WY * WZ;           // 128
+// Round 6, the wave-specialised kernel: the x image is a RING of z planes.  Bricks are walked z-fastest, so a brick's 4-plane
+// halo window shares 2 planes with its predecessor's: only the 2 new planes (12 of 24 halo rows) are fetched, normalised and
+// split per brick -- the operand was 3.4 x redundant (432 halo voxels per 128-voxel brick), now 1.7 x.  8 ring planes: 4 being
+// multiplied, up to 4 being filled (the first brick of a z column fills all 4 and starts 4 planes further on, so it never
+// touches what the previous column's last brick is still being read from).
+constexpr int RZ = 8;                                  // ring planes
+constexpr int XPLANE_R = RZ * WHY * XPITCH * 2 + 16;   // 2320 bytes per channel plane of the ring image (= 145 x 16 B: odd, as 1168 = 73 x 16)
+constexpr int ZSLOT = WHY * XPITCH * 2;                // 288 bytes per ring plane inside a channel plane
 constexpr int WGB_TPB = 512;
 constexpr int MTWB = 2;                    // M tiles per wave (14 tiles over 8 waves)
 
@@ -3028,9 +3036,10 @@ __device__ __forceinline__ unsigned pack2(__bf16 lo, __bf16 hi) {
 // and waves 5-7 share out the five kx = 2 tiles.  Other shapes: round robin.
 struct WgradTiles {
   int TPT, TPK, tile[MTWB], abase[MTWB], akx[MTWB];
+  int akz[MTWB];                                  // ring layout: the lane's tap kz (abase then holds no z term)
   bool share_a;                                   // wave-uniform: tile 1 reuses tile 0's LDS words
 };
-__device__ __forceinline__ WgradTiles wgrad_deal_tiles(int CP, int MT, int TG, int tg, int li, int lh) {
+__device__ __forceinline__ WgradTiles wgrad_deal_tiles(int CP, int MT, int TG, int tg, int li, int lh, bool ring = false) {
   WgradTiles w;
   w.TPT = 32 / CP;
   w.TPK = (9 + w.TPT - 1) / w.TPT;
@@ -3049,6 +3058,11 @@ __device__ __forceinline__ WgradTiles wgrad_deal_tiles(int CP, int MT, int TG, i
     const bool valid = (m < MT) && (t9 < 9);
     const int kz = t9 / 3, ky = t9 % 3;
     w.abase[j] = valid ? (c * XPLANE + (kz * WHY + ky) * (XPITCH * 2) + 16 * lh) : (CP * XPLANE + 16 * lh);
+    w.akz[j] = 0;
+    if (ring) {      // the z offset is added per brick: ((ring base + row plane + kz) mod RZ) planes (the zero plane: any)
+      w.abase[j] = valid ? (c * XPLANE_R + ky * (XPITCH * 2) + 16 * lh) : (CP * XPLANE_R + 16 * lh);
+      w.akz[j] = valid ? kz : 0;
+    }
     w.akx[j] = __builtin_amdgcn_readfirstlane(m < MT ? kx : 0);
   }
   return w;
@@ -3060,18 +3074,24 @@ __device__ __forceinline__ WgradTiles wgrad_deal_tiles(int CP, int MT, int TG, i
 //   1  the paired dealing's waves 0-4: tile 0 is kx = 0 (the words as read), tile 1 is kx = 1 of the SAME words
 //      (4 alignbyte); one LDS read feeds both
 //   2  the paired dealing's waves 5-7: both tiles are kx = 2, a pure register renaming (no VALU)
-template <int NT, int TERMS, int MODE = 0, bool AMP = false>
+template <int NT, int TERMS, int MODE = 0, bool AMP = false, bool RING = false>
 __device__ __forceinline__ void wgrad_mfma_brick(const unsigned char* sXT, const unsigned char* sDT, int xt_bytes,
                                                  const WgradTiles& w, int ks, int KS, int li, int lh,
-                                                 f32x16 (&acc)[MTWB][NT]) {
+                                                 f32x16 (&acc)[MTWB][NT], int ring_base = 0) {
   constexpr int CO = 32 * NT;
   // the paired dealing implies CP = 16 and no k-split (KS = 1): the row loop is unrolled and every LDS offset but the
   // per-lane base is an instruction immediate
-  if (MODE != 0) xt_bytes = 17 * XPLANE;
+  if (MODE != 0) xt_bytes = 17 * (RING ? XPLANE_R : XPLANE);
   const unsigned char* sDTl = sDT + li * DPLANE + 16 * lh;
+  // RING: the byte offset of ring plane (base + zz + kz) mod RZ, per tile and output plane zz of the brick (per lane: kz is)
+  int zo[MTWB][WZ];
+#pragma unroll
+  for (int j = 0; j < MTWB; ++j)
+#pragma unroll
+    for (int z = 0; z < WZ; ++z) zo[j][z] = RING ? ((ring_base + z + w.akz[j]) & (RZ - 1)) * ZSLOT : 0;
   auto one_row = [&](int row) {
     const int zz = row / WY, yy = row - zz * WY;
-    const int arow = (zz * WHY + yy) * (XPITCH * 2);
+    const int arow = RING ? yy * (XPITCH * 2) : (zz * WHY + yy) * (XPITCH * 2);
     const int brow = row * WX * 2;
     bf16x8 b[NT][TERMS];
 #pragma unroll
@@ -3087,7 +3107,7 @@ __device__ __forceinline__ void wgrad_mfma_brick(const unsigned char* sXT, const
 #pragma unroll
       for (int q = 0; q < TERMS; ++q) {
         if (MODE == 1 ? j == 0 : (MODE == 2 || j == 0 || !w.share_a)) {
-          const unsigned char* p = sXT + q * xt_bytes + w.abase[j] + arow;
+          const unsigned char* p = sXT + q * xt_bytes + w.abase[j] + (RING ? zo[j][zz] : 0) + arow;
           wq[q] = *reinterpret_cast<const uint4*>(p);
           w4q[q] = *reinterpret_cast<const unsigned*>(p + 16);
         }
@@ -3449,8 +3469,11 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
     const float* __restrict__ dscale, int dz_blocked /* dz is (N, Cout/8, D, H, W, 8) */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smemb[];
   constexpr int CO = 32 * NT;
-  const int xt_bytes = (CP + 1) * XPLANE;                 // one term of sXT
-  const int buf_bytes = TERMS * (xt_bytes + CO * DPLANE); // one stage: sXT[TERMS][CP+1][XPLANE], sDT[TERMS][CO][DPLANE]
+  // LDS: sXT[TERMS][CP+1][XPLANE_R] -- ONE ring image of RZ z planes (see XPLANE_R) -- then two stages of sDT[TERMS][CO][DPLANE]
+  const int xt_bytes = (CP + 1) * XPLANE_R;               // one term of sXT
+  constexpr int dt_bytes = TERMS * CO * DPLANE;           // one stage of sDT
+  unsigned char* const sXTr = smemb;
+  unsigned char* const sDT0 = smemb + TERMS * xt_bytes;
   constexpr int WS_TPB = 64 * (WS_CONS + PW), WS_PT = 64 * PW;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -3460,14 +3483,13 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
   const int cit = tile % ci_tiles, cog = tile / ci_tiles;
   const int ci0 = cit * CP, co0 = cog * CO;
 
-  // zero plane (padded M rows) of every term, both stages
-  for (int e = tid; e < 2 * TERMS * (XPLANE / 4); e += WS_TPB) {
-    const int st = e / (TERMS * (XPLANE / 4)), r = e - st * (TERMS * (XPLANE / 4));
-    const int t = r / (XPLANE / 4), o = r - t * (XPLANE / 4);
-    reinterpret_cast<unsigned*>(smemb + st * buf_bytes + t * xt_bytes + CP * XPLANE)[o] = 0u;
+  // zero plane (padded M rows) of every term: all RZ ring planes of it
+  for (int e = tid; e < TERMS * (XPLANE_R / 4); e += WS_TPB) {
+    const int t = e / (XPLANE_R / 4), o = e - t * (XPLANE_R / 4);
+    reinterpret_cast<unsigned*>(sXTr + t * xt_bytes + CP * XPLANE_R)[o] = 0u;
   }
   // slabs never straddle samples (nslab_total = N * slabs per sample): the reduce kernel can then give per-sample sums
-  const int bricks_per_n = tiles_x * tiles_y * tiles_z, tiles_xy = tiles_x * tiles_y;
+  const int bricks_per_n = tiles_x * tiles_y * tiles_z;
   const int slabs_per_n = nslab_total / N;
   const long long b_base = (long long)(slab / slabs_per_n) * bricks_per_n;
   const long long b_beg = b_base + (long long)(slab % slabs_per_n) * bricks_per_slab;
@@ -3477,31 +3499,38 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
   auto brick_coords = [&](long long bi64, int& n, int& x0, int& y0, int& z0) {
     const int bi = (int)bi64;
     n = bi / bricks_per_n;
-    const int r = bi - n * bricks_per_n;
-    const int bz = r / tiles_xy, r2 = r - bz * tiles_xy;
-    const int by = r2 / tiles_x, bx = r2 - by * tiles_x;
+    const int r = bi - n * bricks_per_n;                   // z fastest: consecutive bricks share two halo planes
+    const int col = r / tiles_z, bz = r - col * tiles_z;
+    const int by = col / tiles_x, bx = col - by * tiles_x;
     x0 = bx * WX; y0 = by * WY; z0 = bz * WZ;
   };
+  // ring base of a brick: + 2 planes per brick inside a z column, + 4 at the first brick of a column (which fills all four
+  // planes of its window); producers and consumers advance it by the same rule
+  const int cz_first = (int)((b_beg - b_base) % tiles_z);
 
   if (wv >= WS_CONS) {
     // ------------------------------------------------------------------------------ producers
     const int pt = tid - 64 * WS_CONS;
     const int cq = CP >> 2;                               // channel quads per voxel
     const int x_per_row = 9 * cq;
-    const int x_items = XROWS * x_per_row;                // <= 864
-    constexpr int XI = (864 + WS_PT - 1) / WS_PT;         // 4
+    // x items of HALF a halo window (2 planes = 12 rows): set 0 = planes 2, 3 (the NEW planes of every brick), set 1 = planes
+    // 0, 1 (fetched only by the first brick of a z column).  Same (ly, pair, channels) in both sets: lz differs by 2.
+    const int x_items = 2 * WHY * x_per_row;              // <= 432
+    constexpr int XH = (432 + WS_PT - 1) / WS_PT;         // items per thread and half: 1 (PW = 8) or 2
+    constexpr int XI = 2 * XH;                            // register sets: [0, XH) = set 0, [XH, 2 XH) = set 1
     constexpr int DI = (WV / 2) * (CO / 4) / WS_PT;       // 4 (NT = 2) or 2
     int xi_pk[XI], xi_lds[XI];                     // pk = lz | ly << 4 | (2 pr) << 8 | cb << 16 | on << 30 (halo coords)
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const int e = pt + i * WS_PT;
+      const int e = pt + (i % XH) * WS_PT;
       const int rowh = e / x_per_row, rem = e - rowh * x_per_row;
       const int cpart = rem / 9, pr = rem - cpart * 9;
-      const int lz = rowh / WHY, ly = rowh - lz * WHY;
+      const int lzh = rowh / WHY, ly = rowh - lzh * WHY;
+      const int lz = lzh + (i < XH ? 2 : 0);
       const int cb = 4 * cpart;
       const bool on = (e < x_items) && (ci0 + cb < Cin);
       xi_pk[i] = on ? (lz | (ly << 4) | ((2 * pr) << 8) | (cb << 16) | (1 << 30)) : 0;   // off: loads a valid dummy
-      xi_lds[i] = cb * XPLANE + (rowh * XPITCH + 2 * pr) * 2;
+      xi_lds[i] = cb * XPLANE_R + (ly * XPITCH + 2 * pr) * 2;                               // + the ring plane's ZSLOT, per brick
     }
     int di_pk[DI], di_lds[DI], di_q4[DI];
 #pragma unroll
@@ -3526,7 +3555,8 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
     // Loads are unconditional: halo coordinates are clamped into the volume (the value is zeroed at conversion time
     // when the true coordinate was outside), so a brick's 16 (+8 mask) 16-byte loads per thread go out back to back.
     // Element offsets inside one sample are 24-bit multiply-adds (the launcher checks D*H*W*C < 2^31).
-    auto issue = [&](int n, int x0, int y0, int z0) {
+    auto issue = [&](int n, int x0, int y0, int z0, bool col_start) {
+      const int xn_sets = col_start ? XI : XH;             // uniform: a column's first brick fetches all four planes
       const float* xn = x + (long long)n * D * H * W * Cin + ci0;
       const float* dn = DSPLIT ? dz + (long long)n * (Cout >> 3) * ((long long)D * H * W + 1) * 8
                                : dz + (long long)n * D * H * W * Cout + (dz_blocked ? 0 : co0);
@@ -3535,6 +3565,7 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
       unsigned xo[XI][2], dO[DI][2];
 #pragma unroll
       for (int i = 0; i < XI; ++i) {
+        if (i >= xn_sets) break;
         const int gz = min(max(z0 + (xi_pk[i] & 15) - 1, 0), D - 1), gy = min(max(y0 + ((xi_pk[i] >> 4) & 15) - 1, 0), H - 1);
         const int gx0 = x0 + ((xi_pk[i] >> 8) & 255) - 1, cb = (xi_pk[i] >> 16) & 255;
         const unsigned row = __umul24(__umul24(gz, H) + gy, W);
@@ -3551,6 +3582,7 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
       }
 #pragma unroll
       for (int i = 0; i < XI; ++i) {
+        if (i >= xn_sets) break;
         px[i][0] = *reinterpret_cast<const float4*>(xn + xo[i][0]);
         px[i][1] = *reinterpret_cast<const float4*>(xn + xo[i][1]);
       }
@@ -3574,13 +3606,14 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
     // (n, channel) normalisation coefficients of this workgroup's CP channels, pre-multiplied by the range scale:
     // a small LDS table behind the two stages, rewritten (by every producer wave for itself: LDS operations of one
     // wave are ordered, and the waves write identical values) when the sample index changes
-    float* ctab = reinterpret_cast<float*>(smemb + 2 * buf_bytes);
+    float* ctab = reinterpret_cast<float*>(sDT0 + 2 * dt_bytes);
     int tab_n = -1;
     const float relu_lo = relu_in ? 0.f : -INFINITY;
     // Keeps every use of the staged registers behind the barrier: register-only work may otherwise be hoisted above
     // the (volatile, but not register-clobbering) barrier statement, and the wait for the loads with it.
     auto pin = [](float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
-    auto convert = [&](int n, int x0, int y0, int z0, unsigned char* sXT, unsigned char* sDT) {
+    auto convert = [&](int n, int x0, int y0, int z0, unsigned char* sXT, unsigned char* sDT, int ring_base, bool col_start) {
+      const int xn_sets = col_start ? XI : XH;
       if (n != tab_n) {
         tab_n = n;
         if (lane < 2 * CP) {
@@ -3592,6 +3625,8 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
       }
 #pragma unroll
       for (int i = 0; i < XI; ++i) {
+        if (i >= xn_sets) break;
+        const int zdst = ((ring_base + (xi_pk[i] & 15)) & (RZ - 1)) * ZSLOT;      // this halo plane's place in the ring
         const int gz = z0 + (xi_pk[i] & 15) - 1, gy = y0 + ((xi_pk[i] >> 4) & 15) - 1;
         const int gx0 = x0 + ((xi_pk[i] >> 8) & 255) - 1, cb = (xi_pk[i] >> 16) & 255;
         const bool rowok = (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D;
@@ -3615,7 +3650,7 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
             split_pair<TERMS>(v[0][j], v[1][j], w);
 #pragma unroll
             for (int t = 0; t < TERMS; ++t)
-              *reinterpret_cast<unsigned*>(sXT + t * xt_bytes + xi_lds[i] + j * XPLANE) = w[t];
+              *reinterpret_cast<unsigned*>(sXT + t * xt_bytes + xi_lds[i] + zdst + j * XPLANE_R) = w[t];
           }
         }
       }
@@ -3660,18 +3695,24 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
       }
     };
 
-    // brick coordinates advance incrementally (x fastest, then y, z, sample): no divisions in the loop
+    // brick coordinates advance incrementally (z fastest, then x, y; a slab stays inside one sample): no divisions in the loop
     int cn, cx, cy, cz;
     {
       int x0, y0, z0;
       brick_coords(b_beg, cn, x0, y0, z0);
       cx = x0 / WX; cy = y0 / WY; cz = z0 / WZ;
     }
-    issue(cn, cx * WX, cy * WY, cz * WZ);
+    int rbase = 0;                                        // ring base of the brick whose loads are in flight
+    bool cstart = true;                                   // ... and whether it is the first of its column (here: of the slab)
+    issue(cn, cx * WX, cy * WY, cz * WZ, true);
     for (long long bi = b_beg; bi < b_end; ++bi) {
-      unsigned char* base = smemb + ((bi - b_beg) & 1) * buf_bytes;
+      unsigned char* sDTs = sDT0 + ((bi - b_beg) & 1) * dt_bytes;
       const int pn = cn, px0 = cx * WX, py0 = cy * WY, pz0 = cz * WZ;      // the brick whose loads are in flight
-      if (++cx == tiles_x) { cx = 0; if (++cy == tiles_y) { cy = 0; if (++cz == tiles_z) { cz = 0; ++cn; } } }
+      const int pbase = rbase;
+      const bool pstart = cstart;
+      cstart = false;
+      if (++cz == tiles_z) { cz = 0; cstart = true; if (++cx == tiles_x) { cx = 0; if (++cy == tiles_y) { cy = 0; ++cn; } } }
+      rbase = (rbase + (cstart ? 4 : 2)) & (RZ - 1);
 #pragma unroll
       for (int i = 0; i < XI; ++i) { pin(px[i][0]); pin(px[i][1]); }
 #pragma unroll
@@ -3679,8 +3720,8 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
         pin(pd[i][0]); pin(pd[i][1]);
         if (MASK) { pin(pm[i][0]); pin(pm[i][1]); }
       }
-      convert(pn, px0, py0, pz0, base, base + TERMS * xt_bytes);            // waits for the loads of brick bi only
-      if (bi + 1 < b_end) issue(cn, cx * WX, cy * WY, cz * WZ);             // in flight across the barrier
+      convert(pn, px0, py0, pz0, sXTr, sDTs, pbase, pstart);                 // waits for the loads of brick bi only
+      if (bi + 1 < b_end) issue(cn, cx * WX, cy * WY, cz * WZ, cstart);      // in flight across the barrier
       ws_barrier();
     }
     return;
@@ -3688,7 +3729,7 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
 
   // -------------------------------------------------------------------------------- consumers
   const int tg = wv % TG, ks = wv / TG;
-  const WgradTiles wt = wgrad_deal_tiles(CP, MT, TG, tg, li, lh);
+  const WgradTiles wt = wgrad_deal_tiles(CP, MT, TG, tg, li, lh, true);
   f32x16 acc[MTWB][NT];
 #pragma unroll
   for (int j = 0; j < MTWB; ++j)
@@ -3699,11 +3740,14 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
 
   ws_barrier();                                            // brick b_beg is staged (and the zero planes written)
   auto bricks = [&](auto mode) {
+    int rbase = 0, cz = cz_first;                           // as the producers count them
     for (long long bi = b_beg; bi < b_end; ++bi) {
-      const unsigned char* sXT = smemb + ((bi - b_beg) & 1) * buf_bytes;
-      const unsigned char* sDT = sXT + TERMS * xt_bytes;
-      wgrad_mfma_brick<NT, TERMS, decltype(mode)::value, AMP>(sXT, sDT, xt_bytes, wt, ks, KS, li, lh, acc);
-      if (bi + 1 < b_end) ws_barrier();                    // brick bi+1 is staged, stage (bi & 1) may be overwritten
+      const unsigned char* sDT = sDT0 + ((bi - b_beg) & 1) * dt_bytes;
+      wgrad_mfma_brick<NT, TERMS, decltype(mode)::value, AMP, true>(sXTr, sDT, xt_bytes, wt, ks, KS, li, lh, acc, rbase);
+      const bool nstart = ++cz == tiles_z;
+      if (nstart) cz = 0;
+      rbase = (rbase + (nstart ? 4 : 2)) & (RZ - 1);
+      if (bi + 1 < b_end) ws_barrier();                    // brick bi+1 is staged: its ring planes and the other sDT stage
     }
   };
   // the paired dealing (CP = 16) fixes every wave's tap x offsets: waves 0-4 hold (kx 0, kx 1) of one slot, waves
@@ -3784,7 +3828,8 @@ __global__ __launch_bounds__(1024) void wgrad_bf_reduce_fold_kernel(const float*
 struct WgradBfPlan {
   int CP, MT, TG, KS, ci_tiles, co_groups, NT, tiles_x, tiles_y, tiles_z, nslab, bricks_per_slab;
   long long nbricks;
-  size_t lds;
+  size_t lds;        // one stage of conv3_wgrad_bf_kernel
+  size_t lds_ws;     // conv3_wgrad_ws_kernel: the ring x image + two dz stages + the coefficient table
 };
 
 static WgradBfPlan wgrad_bf_plan(int N, int D, int H, int W, int Cin, int Cout, int terms) {
@@ -3811,6 +3856,7 @@ static WgradBfPlan wgrad_bf_plan(int N, int D, int H, int W, int Cin, int Cout, 
   p.bricks_per_slab = (int)((bricks_per_n + want - 1) / want);
   p.nslab = N * (int)((bricks_per_n + p.bricks_per_slab - 1) / p.bricks_per_slab);
   p.lds = (size_t)terms * ((size_t)(p.CP + 1) * XPLANE + (size_t)32 * p.NT * DPLANE);
+  p.lds_ws = (size_t)terms * ((size_t)(p.CP + 1) * XPLANE_R + 2 * (size_t)32 * p.NT * DPLANE) + 256;
   return p;
 }
 
@@ -3834,7 +3880,7 @@ template <int NT, int TERMS, bool MASK, int PW, bool DSPLIT = false>
 static int launch_wgrad_ws(const WgradBfPlan& p, const float* x, const float* scale, const float* shift,
                            const float* dz, const float* dzmask, float* ws, int N, int D, int H, int W, int Cin,
                            int Cout, int relu_in, const float* xscale, const float* dscale, int dz_blocked, hipStream_t s) {
-  const size_t lds = 2 * p.lds + 256;                      // two stages + the coefficient table
+  const size_t lds = p.lds_ws;                             // ring x image, two dz stages, the coefficient table
   hipError_t e = hipFuncSetAttribute((const void*)conv3_wgrad_ws_kernel<NT, TERMS, MASK, PW, DSPLIT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
@@ -3862,7 +3908,7 @@ static int launch_wgrad_ws(const WgradBfPlan& p, const float* x, const float* sc
 // the wave-specialised kernel's preconditions (vector path of the f16x3 mode)
 static bool wgrad_ws_ok(const WgradBfPlan& p, int D, int H, int W, int Cin, int Cout, int terms) {
   static const bool no_ws = getenv("KEYMORPH_WGRAD_NO_WS") != nullptr;     // A/B measurements only
-  return !no_ws && terms == 2 && p.CP >= 4 && (Cin & 3) == 0 && (Cout & 3) == 0 && 2 * p.lds + 256 <= 160 * 1024 &&
+  return !no_ws && terms == 2 && p.CP >= 4 && (Cin & 3) == 0 && (Cout & 3) == 0 && p.lds_ws <= 160 * 1024 &&
          (long long)D * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31) &&
          (long long)D * H * W <= (1ll << 24);   // 24-bit multiply-adds index the voxels of one sample
 }

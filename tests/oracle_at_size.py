@@ -308,3 +308,30 @@ def oracle_tps_step(size, keypoints, lam, sd_seed=23, seed=100, threads=32, in_s
             "grads": {k: v.grad.detach() for k, v in sd.items()}, "loss": float(loss.detach()), "points_f": pf.detach(),
             "points_m": pm.detach(), "idx": idx, "grid_samples": grid.detach()[0][idx[0], idx[1], idx[2]],
             "size": size, "keypoints": keypoints, "lam": float(lam)}
+
+
+def oracle_cfg1_fp64(threads=32, in_subprocess=True):
+    """BASELINE configs[0] end to end -- the example_data_half pair at 128^3 (label / 13 intensities from the fixture
+    tests/golden/cfg1_example_half_128.npz), 128 keypoints, affine, MSE, loss.backward() (scripts/train.py:129-176) -- by the
+    oracle's autograd in fp32 (the reference arithmetic) AND in fp64 (truth) from the same fp32 weights and images: the
+    per-tensor parameter gradients both ways.  ~15 GB of host RAM, about a minute; child process by default (see oracle_pair)."""
+    if in_subprocess:
+        return _child(f"oracle_cfg1_fp64({threads}, False)", threads)
+    from oracle import keymorph_oracle as O
+    from tests.util import golden
+    K = 128
+    g = golden("cfg1_example_half_128.npz")
+    img_f = (torch.from_numpy(g["label_0"]).float() / 13.0)[None, None]
+    img_m = (torch.from_numpy(g["label_1"]).float() / 13.0)[None, None]
+    sd0 = seeded_state_dict(unet_shapes(K, 32, trunc=1), 23)
+    out = {"sd": sd0}
+    for name, dt in (("fp32", torch.float32), ("fp64", torch.float64)):
+        sd = {k: v.detach().to(dt).clone().requires_grad_(True) for k, v in sd0.items()}
+        f, m = img_f.to(dt), img_m.to(dt)
+        r = O.keymorph_forward(lambda x: O.unet3d_forward(sd, x, 4, 1, 8), f, m, "affine", True)
+        mse = O.mse_loss(f, O.align_img(r["grid"], m))
+        mse.backward()
+        out["mse_" + name] = mse.detach()
+        out["points_f_" + name] = r["points_f"].detach()
+        out["grads_" + name] = {k: v.grad.detach() for k, v in sd.items()}
+    return out

@@ -65,18 +65,35 @@ def test_cfg1_128_affine_vs_reference_and_oracle():
     close(mse, g["mse"], 1e-5)
     close(dice, g["softdiceloss"], 1e-4)
     close(hard, g["harddiceloss"], 1e-4)
-    worst = 0.0
-    for k, p in net.named_parameters():
-        ref = g[f"gradsum::{k}"]
-        worst = max(worst, abs(float(p.grad.norm()) - float(ref[2])) / (float(ref[2]) + 1e-30))
     e_b = rel_l2(net.final_conv.bias.grad, g["gradfull::final_conv.bias"])
     e_0 = rel_l2(net.encoders[0].basic_module.SingleConv1.conv.weight.grad, g["gradfull::enc0"])
-    print(f"cfg1: parameter-gradient norms within {worst:.2e} of the reference's; rel-L2 final bias {e_b:.2e}, "
+    print(f"cfg1: rel-L2 against the two full gradient tensors the REFERENCE run left in the fixture: final bias {e_b:.2e}, "
           f"first conv {e_0:.2e}")
-    # 128^3 x 32..256 channels of piecewise-constant label images put a few hundred pre-ReLU values at rounding distance
-    # from zero, where any two fp32 implementations mask differently; the strict per-tensor bars (1e-3 / 1e-5 with the
-    # ReLU-kink accounting) are asserted at sizes the fp64 oracle can audit: tests/test_parity_r2_gpu.py
-    assert worst < 3e-2 and e_b < 1e-2 and e_0 < 1e-2, (worst, e_b, e_0)
+    assert e_b < 1e-2 and e_0 < 1e-2, (e_b, e_0)
+    # Every parameter-gradient tensor against the FP64 run of the oracle on this very pair (round 6; until round 5 the bar
+    # here was "gradient norms within 3e-2 of the reference's").  128^3 x 32..256 channels of piecewise-constant label
+    # images put a few hundred pre-ReLU values at rounding distance from zero, where any fp32 implementation masks
+    # differently from fp64 -- the oracle's own fp32 autograd is measured against the same truth and sets the scale:
+    # per tensor |hip - fp64| <= max(3e-3, 3 |oracle fp32 - fp64|) relative L2, the whole vector <= max(1e-3, 2 x the oracle's).
+    from tests.oracle_at_size import oracle_cfg1_fp64
+    ref = oracle_cfg1_fp64()
+    g64, g32 = ref["grads_fp64"], ref["grads_fp32"]
+    assert abs(float(mse) - float(ref["mse_fp64"])) <= 1e-6
+    rows, nh, no_, den = [], 0.0, 0.0, 0.0
+    for k, p in net.named_parameters():
+        t = g64[k].double()
+        eh = float((p.grad.detach().cpu().double() - t).norm() / (t.norm() + 1e-300))
+        eo = float((g32[k].double() - t).norm() / (t.norm() + 1e-300))
+        rows.append((k, eh, eo))
+        nh += float((p.grad.detach().cpu().double() - t).pow(2).sum()); no_ += float((g32[k].double() - t).pow(2).sum())
+        den += float(t.pow(2).sum())
+    whole_h, whole_o = (nh / den) ** 0.5, (no_ / den) ** 0.5
+    print(f"cfg1 parameter gradients vs fp64: whole vector hip {whole_h:.2e}, oracle fp32 {whole_o:.2e}")
+    for k, eh, eo in sorted(rows, key=lambda r_: -r_[1])[:8]:
+        print(f"   {k:62s} hip {eh:.2e}   oracle fp32 {eo:.2e}")
+    worse = [(k, eh, eo) for k, eh, eo in rows if eh > max(3e-3, 3 * eo)]
+    assert not worse, worse
+    assert whole_h <= max(1e-3, 2 * whole_o), (whole_h, whole_o)
 
     # (ii) against the oracle on the host cores (forward only: ~10 s)
     with torch.no_grad():

@@ -11,7 +11,7 @@ objs=""
 for f in $out/src/keymorph_amd/csrc/*.hip; do
   o=$out/$(basename ${f%.hip}).o
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fvisibility=hidden -Wno-unused-result -Wno-unused-value \
-    -ffp-contract=fast -I$out/src/include -c $f -o $o &
+    -ffp-contract=fast -I$out/src/include $( case $(basename $f) in conv_wgrad.hip|norm.hip) echo "-mllvm -amdgpu-sched-strategy=max-ilp";; esac ) -c $f -o $o &
   objs="$objs $o"
 done
 wait

@@ -10,8 +10,10 @@ for d in sys.argv[1:]:
             k = re.sub(r"^void ", "", k).split("(")[0]
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k].add(r["Dispatch_Id"])
+import os
+ONLY = tuple(t for t in os.environ.get("KMH_PMC_ONLY", "").split(",") if t)      # e.g. KMH_PMC_ONLY=sample_,warp_
 for k, v in agg.items():
-    if not any(t in k for t in ("conv3", "headcom", "tps", "sample", "warp_dice", "dice_partial", "elementwise", "copy")):
+    if not any(t in k for t in (ONLY or ("conv3", "headcom", "tps", "sample", "warp_dice", "dice_partial", "elementwise", "copy"))):
         continue
     print(f"{k}   [{len(cnt[k])} dispatches]")
     for c, x in sorted(v.items()):

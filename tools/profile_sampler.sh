@@ -35,10 +35,10 @@ run_grp() {   # $1 label; rest command
       echo "   (pass failed: $P :: $(grep -i -m1 'error\|invalid\|not found' gpurun_out/sp_log.txt))" >> $out
     fi
   done
-  python tools/pmc_agg.py $dirs >> $out
+  KMH_PMC_ONLY=sample_,warp_ python tools/pmc_agg.py $dirs >> $out
   for i in $(seq 1 ${#GROUPS_[@]}); do rm -rf gpurun_out/sp_$i; done
   rm -f gpurun_out/sp_log.txt
 }
 echo "== python tools/bench_sampler.py 256 (times without a profiler)" >> $out
 GRID=affine3 python tools/bench_sampler.py 256 >> $out 2>&1
-GRID=affine3 run_grp "GRID=affine3 python tools/bench_sampler.py 256 (every launch of the script summed per kernel; launches per kernel: see the script)" python tools/bench_sampler.py 256
+KMH_SAMPLER_QUICK=1 GRID=affine3 run_grp "KMH_SAMPLER_QUICK=1 GRID=affine3 python tools/bench_sampler.py 256 (every launch of the script summed per kernel; dispatches per kernel in brackets)" python tools/bench_sampler.py 256
