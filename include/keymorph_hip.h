@@ -28,11 +28,6 @@ extern "C" {
 #define KMH_ABI_VERSION 1
 int kmh_abi_version(void);
 
-/* Kernel selection of the bilinear warp behind kmh_grid_sample3d_fwd (C = 1), kmh_warp_mse_fwd and kmh_warp_mse_fwd_grad
- * (one grid_sample in the reference: keymorph/utils.py:14-21; the implementations give bit-identical outputs): 0 = one
- * 1024-voxel chunk per workgroup, 2 / 4 = the persistent kernel with 2 / 4 voxels of a lane in flight (round 6).  KMH_SAMPLER_P
- * sets the initial value.  Returns the previous setting, -22 for a bad argument. */
-int kmh_sampler_set_persistent(int ilp);
 /* ---- a11: align_img = F.grid_sample(bilinear|nearest, border, align_corners=False)
  *      keymorph/utils.py:14-21.  x (N,C,D,H,W); grid (N,Do,Ho,Wo,3) xyz; out (N,C,Do,Ho,Wo).
  *      mode: 0 bilinear, 1 nearest. */

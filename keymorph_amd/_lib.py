@@ -66,7 +66,6 @@ PROTOS = {
     "kmh_conv3d_pack_bf_bytes": (_sz, [_i, _i, _i, _i]),
     "kmh_conv3d_pack_weight_bf": (_i, [_f, _f, _i, _i, _i, _i, _f, _f]),
     "kmh_conv3d_fwd_bf": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f]),
-    "kmh_sampler_set_persistent": (_i, [_i]),
     "kmh_conv3d_fwd_bf_set_dispatch": (_i, [_i]),
     "kmh_conv3d_fwd_bf_variant": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "kmh_conv3d_fwd_bf_pool_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),

@@ -7,14 +7,10 @@
 // owns VPT=4 consecutive output voxels so the grid is read as 3 x 16-B loads and the output
 // written as one 16-B store per channel.
 #include "common.h"
-#include <atomic>
 #include <cstdlib>
 
 namespace {
 
-#ifndef KMH_SAMPLER_P_DEFAULT
-#define KMH_SAMPLER_P_DEFAULT 0      // set after the A/B measurement (profiles/r6*_sampler_persistent.txt)
-#endif
 constexpr int VPT = 4;      // voxels per thread
 constexpr int TPB = 256;    // threads per block
 
@@ -558,133 +554,6 @@ __device__ __forceinline__ ChunkWalk chunk_walk(int b, int nb, int nchunk) {
   w.step = (nb - xcd + NX - 1) / NX;          // blocks of this launch row that sit on this XCD
   w.cur = lo + idx;
   return w;
-}
-
-// ----------------------------------------------------------------------------------------------
-// Round 6: the PERSISTENT form of sample_fwd_lc_kernel (bilinear; C = 1 warps and the fused warp + MSE (+ d loss / d grid)
-// of the training step).  Counters of the one-chunk-per-workgroup kernel (profiles/r6*_sampler_counters.txt): 5 of 8 waves
-// per SIMD resident, 116 VALU + 44 SALU per voxel, 37 % of the wave cycles waiting on memory, 13 % issuing -- a workgroup's
-// life is three dependent memory round trips (grid rows -> LDS, two sub-passes of gathers) plus its launch and teardown,
-// and nothing of one chunk overlaps the next.  Here a workgroup walks many chunks: the NEXT chunk's grid rows are fetched
-// into registers before this chunk's gathers (as the fused Dice kernels do), the gathers are buffer loads (scalar plane
-// base + 32-bit byte offsets: no 64-bit address arithmetic, no clamped addresses for lanes past the end), and with ILP = 4
-// all 16 pair-gathers of a lane's four voxels are in flight together (one round trip per chunk instead of two).
-// Outputs and d(loss)/d(grid) are bit-identical to sample_fwd_lc_kernel (same taps, same blend8 chain); the MSE partial of a
-// workgroup is the double sum of its lanes' per-chunk fp32 sums (the old kernel: one chunk per workgroup, same per-lane sums).
-template <bool FUSE_MSE, bool FUSE_GRAD, int ILP>
-__global__ __launch_bounds__(TPB) void sample_fwd_p_kernel(
-    const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ out,
-    const float* __restrict__ fixed, double* __restrict__ partial, int C, int D, int H, int W, long long ovox, int nchunk,
-    float* __restrict__ dgrid = nullptr, float gcoef = 0.f /* 2 / (N C voxels) */) {
-  __shared__ __attribute__((aligned(16))) float sg[TPB * PASSES * 3];
-  const int n = blockIdx.y, tid = threadIdx.x;
-  const long long plane = (long long)D * H * W;
-  const unsigned plane_bytes = (unsigned)(plane * 4);
-  const float* gbase = grid + (long long)n * ovox * 3;
-  const ChunkWalk cw = chunk_walk(blockIdx.x, gridDim.x, nchunk);
-  int chunk = cw.cur;
-  GridRows nxt = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-  bool nfast = false;
-  if (chunk < cw.end) {
-    const long long vb = (long long)chunk * (TPB * PASSES);
-    const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
-    nfast = rows_fast(gbase + vb * 3, cnt);
-    fetch_rows(gbase + vb * 3, nfast, nxt, tid);
-  }
-  double dacc = 0.0;
-#pragma unroll 1
-  for (; chunk < cw.end; chunk += cw.step) {
-    const long long vb = (long long)chunk * (TPB * PASSES);
-    const int cnt = ovox - vb < TPB * PASSES ? (int)(ovox - vb) : TPB * PASSES;
-    __syncthreads();                                  // the previous chunk's readers (and its gradient write-back) are done
-    commit_rows(gbase + vb * 3, cnt, nfast, nxt, sg, tid);
-    __syncthreads();
-    {                                                 // the next chunk's rows: in flight under this chunk's gathers
-      const int c2 = chunk + cw.step;
-      if (c2 < cw.end) {
-        const long long vb2 = (long long)c2 * (TPB * PASSES);
-        const int cnt2 = ovox - vb2 < TPB * PASSES ? (int)(ovox - vb2) : TPB * PASSES;
-        nfast = rows_fast(gbase + vb2 * 3, cnt2);
-        fetch_rows(gbase + vb2 * 3, nfast, nxt, tid);
-      }
-    }
-    float acc = 0.f;
-#pragma unroll 1
-    for (int j0 = 0; j0 < PASSES; j0 += ILP) {
-      Tap t[ILP];
-      TapB q[ILP];
-#pragma unroll
-      for (int u = 0; u < ILP; ++u) {
-        const int l = tid + (j0 + u) * TPB;
-        t[u] = make_tap(sg[l * 3], sg[l * 3 + 1], sg[l * 3 + 2], D, H, W);
-        q[u] = make_tapb(t[u], D, H, W);
-        if (l >= cnt) {     // past the chunk: every corner reads 0 through the range check, the weights must be finite
-          q[u].o00 = q[u].o01 = q[u].o10 = q[u].o11 = plane_bytes;
-          q[u].fx = q[u].fy = q[u].fz = 0.f;
-          t[u].fx = t[u].fy = t[u].fz = 0.f;
-        }
-      }
-      const int left = cnt - j0 * TPB;                 // voxels of the chunk from this sub-pass on (may be <= 0)
-      const unsigned fbytes = left > 0 ? 4u * (unsigned)left : 0u;
-      float ggx[ILP], ggy[ILP], ggz[ILP];
-#pragma unroll
-      for (int u = 0; u < ILP; ++u) ggx[u] = ggy[u] = ggz[u] = 0.f;
-#pragma unroll 1
-      for (int c = 0; c < C; ++c) {
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + ((long long)n * C + c) * plane, plane_bytes);
-        const long long ob = ((long long)n * C + c) * ovox + vb;
-        float v[ILP][8], fv[ILP], o[ILP];
-        if (FUSE_MSE) {
-          const __amdgpu_buffer_rsrc_t rf = make_rsrc(fixed + ob + j0 * TPB, fbytes);
-#pragma unroll
-          for (int u = 0; u < ILP; ++u)
-            fv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, 4 * (tid + u * TPB), 0, 0));
-        }
-#pragma unroll
-        for (int u = 0; u < ILP; ++u) gather8_b(rx, q[u], v[u]);
-#pragma unroll
-        for (int u = 0; u < ILP; ++u) {
-          // (the far-border corners: make_tapb clamps y1 / z1 onto the border row, where fy / fz = 0 -- the same products as
-          // sample_fwd_lc_kernel's oy / oz zeros, bit for bit: 0 * finite = 0 in both)
-          o[u] = blend8(v[u], t[u]);
-        }
-        if (FUSE_GRAD) {
-#pragma unroll
-          for (int u = 0; u < ILP; ++u) {
-            float dx, dy, dz;
-            blend_grads(v[u], t[u], dx, dy, dz);
-            const float go = (tid + (j0 + u) * TPB < cnt) ? (o[u] - fv[u]) * gcoef : 0.f;
-            ggx[u] += dx * go; ggy[u] += dy * go; ggz[u] += dz * go;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < ILP; ++u) {
-          const int l = tid + (j0 + u) * TPB;
-          if (l < cnt) {
-            if (FUSE_MSE) { const float d = o[u] - fv[u]; acc += d * d; }
-            if (out) out[ob + l] = o[u];
-          }
-        }
-      }
-      if (FUSE_GRAD) {      // each lane owns its rows of sg: coordinates in, gradient out
-#pragma unroll
-        for (int u = 0; u < ILP; ++u) {
-          const int l = tid + (j0 + u) * TPB;
-          sg[l * 3] = ggx[u] * t[u].mx; sg[l * 3 + 1] = ggy[u] * t[u].my; sg[l * 3 + 2] = ggz[u] * t[u].mz;
-        }
-      }
-    }
-    if (FUSE_MSE) dacc += (double)acc;
-    if (FUSE_GRAD) {
-      __syncthreads();
-      unstage_rows(dgrid + ((long long)n * ovox + vb) * 3, cnt, sg, tid);
-    }
-  }
-  if (FUSE_MSE) {
-    __shared__ double red[TPB / kWave];
-    const double sacc = block_sum<double>(dacc, red);
-    if (threadIdx.x == 0) partial[(long long)blockIdx.y * gridDim.x + blockIdx.x] = sacc;
-  }
 }
 
 // LAB variants: both segmentations are exactly one-hot (what scripts/train.py:54-79 builds: one_hot of a label map,
@@ -1446,66 +1315,7 @@ static bool lane_contiguous_ok(int D, int H, int W) {
   return !force_old && W >= 2 && (long long)D * H * W < (1ll << 31);
 }
 
-// Persistent bilinear sampler (sample_fwd_p_kernel): KMH_SAMPLER_P = 0 (the one-chunk-per-workgroup kernel, the A/B arm) | 2 |
-// 4 (voxels of a lane in flight together).  Its 32-bit byte offsets need < 2^30 voxels per plane; the MSE partials -- one per
-// workgroup -- fit the reduction workspace by construction (<= 2048 workgroups).
-static std::atomic<int> g_sampler_p{-1};
-static int sampler_p_ilp() {
-  int v = g_sampler_p.load(std::memory_order_relaxed);
-  if (v < 0) {
-    v = getenv("KMH_SAMPLER_P") ? atoi(getenv("KMH_SAMPLER_P")) : KMH_SAMPLER_P_DEFAULT;
-    v = (v == 2 || v == 4) ? v : 0;
-    g_sampler_p.store(v, std::memory_order_relaxed);
-  }
-  return v;
-}
-static bool sampler_p_ok(int N, int D, int H, int W, long long ovox) {
-  return sampler_p_ilp() != 0 && lane_contiguous_ok(D, H, W) && (long long)D * H * W < (1ll << 30) && ovox < (1ll << 30) && N <= 256;
-}
-// resident workgroups of the chip for one instance: CUs x the occupancy query (a workgroup = one wave per SIMD), cached per
-// instance; KMH_SAMPLER_P_BLOCKS overrides (A/B runs).  A persistent launch larger than that would run its tail in a second wave.
-template <bool FUSE_MSE, bool FUSE_GRAD, int ILP>
-static int sampler_p_resident() {
-  static const int v = [] {
-    if (getenv("KMH_SAMPLER_P_BLOCKS")) return atoi(getenv("KMH_SAMPLER_P_BLOCKS"));
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)sample_fwd_p_kernel<FUSE_MSE, FUSE_GRAD, ILP>, TPB, 0) != hipSuccess)
-      per_cu = 2;
-    return (cus > 0 ? cus : 256) * (per_cu > 0 ? per_cu : 1);
-  }();
-  return v;
-}
-template <bool FUSE_MSE, bool FUSE_GRAD>
-static dim3 launch_sampler_p(int N, hipStream_t s, const float* x, const float* grid, float* out, const float* fixed, double* partial,
-                             int C, int D, int H, int W, long long ovox, float* dgrid, float gcoef) {
-  const int nchunk = (int)ceil_div(ovox, (long long)TPB * PASSES);
-  const bool four = sampler_p_ilp() == 4;
-  const int capa = four ? sampler_p_resident<FUSE_MSE, FUSE_GRAD, 4>() : sampler_p_resident<FUSE_MSE, FUSE_GRAD, 2>();
-  long long nb = (capa / N) & ~7;                  // a multiple of 8 per sample row: blockIdx.x % 8 is the XCD
-  if (nb < 8) nb = 8;
-  if (nb > nchunk) nb = nchunk;
-  if (nb * N > 65536) nb = 65536 / N;              // one MSE partial per workgroup inside the reduction workspace
-  const dim3 g((unsigned)nb, (unsigned)N);
-  if (four)
-    sample_fwd_p_kernel<FUSE_MSE, FUSE_GRAD, 4><<<g, TPB, 0, s>>>(x, grid, out, fixed, partial, C, D, H, W, ovox, nchunk, dgrid, gcoef);
-  else
-    sample_fwd_p_kernel<FUSE_MSE, FUSE_GRAD, 2><<<g, TPB, 0, s>>>(x, grid, out, fixed, partial, C, D, H, W, ovox, nchunk, dgrid, gcoef);
-  return g;
-}
-
 KMH_API int kmh_abi_version(void) { return 1; }
-
-/* Kernel selection of the bilinear warp (kmh_grid_sample3d_fwd at C = 1, kmh_warp_mse_fwd, kmh_warp_mse_fwd_grad; the reference
- * has one grid_sample: keymorph/utils.py:14-21 -- this only chooses between implementations with bit-identical outputs):
- * 0 = one 1024-voxel chunk per workgroup (sample_fwd_lc_kernel), 2 / 4 = the persistent kernel with 2 / 4 voxels of a lane in
- * flight (sample_fwd_p_kernel).  KMH_SAMPLER_P sets the initial value.  Returns the previous setting, -22 for a bad argument. */
-KMH_API int kmh_sampler_set_persistent(int ilp) {
-  if (ilp != 0 && ilp != 2 && ilp != 4) return -22;
-  const int old = sampler_p_ilp();
-  g_sampler_p.store(ilp, std::memory_order_relaxed);
-  return old;
-}
 
 KMH_API size_t kmh_reduce_ws_bytes(void) { return (size_t)65536 * sizeof(double) * 3; }
 
@@ -1533,10 +1343,6 @@ KMH_API int kmh_grid_sample3d_fwd(const float* x, const float* grid, float* out,
       return KMH_LAUNCH_CHECK();
     }
   }
-  if (mode == 0 && sampler_p_ok(N, D, H, W, ovox)) {
-    launch_sampler_p<false, false>(N, s, x, grid, out, nullptr, nullptr, C, D, H, W, ovox, nullptr, 0.f);
-    return KMH_LAUNCH_CHECK();
-  }
   if (lane_contiguous_ok(D, H, W)) {
     if (mode == 0)
       sample_fwd_lc_kernel<0, false><<<g, TPB, 0, s>>>(x, grid, out, nullptr, nullptr, C, D, H, W, ovox);
@@ -1557,11 +1363,6 @@ KMH_API int kmh_warp_mse_fwd(const float* x, const float* grid, const float* fix
   dim3 g(ceil_div(ovox, (long long)TPB * VPT), N);
   if ((long long)g.x * g.y > 65536 * 3) return -22;
   hipStream_t s = (hipStream_t)stream;
-  if (sampler_p_ok(N, D, H, W, ovox)) {
-    const dim3 gp = launch_sampler_p<true, false>(N, s, x, grid, out, fixed, (double*)ws, C, D, H, W, ovox, nullptr, 0.f);
-    finalize_mean_kernel<<<1, TPB, 0, s>>>((const double*)ws, (int)(gp.x * gp.y), 1.0 / ((double)N * C * (double)ovox), out_loss);
-    return KMH_LAUNCH_CHECK();
-  }
   if (lane_contiguous_ok(D, H, W)) {
     sample_fwd_lc_kernel<0, true><<<g, TPB, 0, s>>>(x, grid, out, fixed, (double*)ws, C, D, H, W, ovox);
   } else {
@@ -1598,11 +1399,6 @@ KMH_API int kmh_warp_mse_fwd_grad(const float* x, const float* grid, const float
   if ((long long)g.x * g.y > 65536 * 3 || !lane_contiguous_ok(D, H, W)) return -22;
   hipStream_t s = (hipStream_t)stream;
   const double cnt = (double)N * C * (double)ovox;
-  if (sampler_p_ok(N, D, H, W, ovox)) {
-    const dim3 gp = launch_sampler_p<true, true>(N, s, x, grid, out, fixed, (double*)ws, C, D, H, W, ovox, dgrid, (float)(2.0 / cnt));
-    finalize_mean_kernel<<<1, TPB, 0, s>>>((const double*)ws, (int)(gp.x * gp.y), 1.0 / cnt, out_loss);
-    return KMH_LAUNCH_CHECK();
-  }
   sample_fwd_lc_kernel<0, true, true><<<g, TPB, 0, s>>>(x, grid, out, fixed, (double*)ws, C, D, H, W, ovox, dgrid,
                                                         (float)(2.0 / cnt));
   finalize_mean_kernel<<<1, TPB, 0, s>>>((const double*)ws, (int)(g.x * g.y), 1.0 / cnt, out_loss);

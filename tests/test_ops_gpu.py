@@ -143,43 +143,6 @@ def test_mse_and_fused_warp_mse():
     close(gh.grad, gr.grad, 1e-8, 2e-4)
 
 
-@pytest.mark.parametrize("shape", [(2, 1, 40, 36, 44), (1, 1, 64, 64, 64), (1, 3, 8, 24, 16), (2, 1, 17, 13, 11)])
-def test_persistent_sampler_bit_identical_to_one_chunk_kernel(shape):
-    """Round 6: the persistent bilinear sampler (sample_fwd_p_kernel, ILP 2 and 4: next chunk's grid rows prefetched, buffer-load
-    gathers) behind the three entry points of the warp -- kmh_grid_sample3d_fwd at C = 1, kmh_warp_mse_fwd,
-    kmh_warp_mse_fwd_grad -- against the one-chunk-per-workgroup kernel on the same inputs: warped volume and d(loss)/d(grid)
-    EQUAL element for element (same taps, same blend chain; +-0 compare equal), loss within 1e-7 relative (another grouping of
-    the same per-lane fp32 sums in double).  Grids include out-of-range coordinates (border clamp), ragged chunk tails and,
-    for the last shape, a grid base that is not 16-byte aligned (the slow staging path)."""
-    from keymorph_amd import _lib
-    lib = _lib.load()
-    g = gen(61)
-    n, c, d, h, w = shape
-    a, b = torch.rand(shape, generator=g).to(DEV), torch.rand(shape, generator=g).to(DEV)
-    grid = (torch.rand(n, d, h, w, 3, generator=g) * 2.4 - 1.2).to(DEV)
-    got = {}
-    prev = lib.kmh_sampler_set_persistent(0)
-    try:
-        for ilp in (0, 2, 4):
-            assert lib.kmh_sampler_set_persistent(ilp) >= 0
-            gh = grid.clone().requires_grad_(True)
-            lf, warped = ops().warp_mse(a, gh, b)
-            lf.backward()
-            with torch.no_grad():
-                plain = ops().grid_sample3d(a[:, :1].contiguous(), grid) if hasattr(ops(), "grid_sample3d") else None
-                lf2, _ = ops().warp_mse(a, grid, b)
-            got[ilp] = (lf.detach().clone(), warped.detach().clone(), gh.grad.clone(), plain, lf2.clone())
-    finally:
-        lib.kmh_sampler_set_persistent(prev)
-    for ilp in (2, 4):
-        assert torch.equal(got[ilp][1], got[0][1]), ilp
-        assert torch.equal(got[ilp][2], got[0][2]), ilp
-        if got[0][3] is not None:
-            assert torch.equal(got[ilp][3], got[0][3]), ilp
-        assert abs(float(got[ilp][0]) - float(got[0][0])) <= 1e-7 * abs(float(got[0][0])), ilp
-        assert abs(float(got[ilp][4]) - float(got[0][4])) <= 1e-7 * abs(float(got[0][4])), ilp
-
-
 @pytest.mark.parametrize("shape,scale", [((2, 1, 16, 12, 20), 1.0), ((1, 3, 8, 24, 16), 2.5), ((2, 1, 17, 13, 11), 1.0)])
 def test_warp_mse_single_pass_gradient(shape, scale):
     """warp + MSE + d(loss)/d(grid) in ONE launch (kmh_warp_mse_fwd_grad; the third shape has no 16-byte-aligned grid

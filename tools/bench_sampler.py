@@ -35,20 +35,16 @@ def timeit(fn, n=30, reps=5):
         b.record(); torch.cuda.synchronize()
         best = min(best, a.elapsed_time(b) / n)
     return best
-VARIANTS = [int(v) for v in os.environ.get("KMH_SAMPLER_VARIANTS", "0,2,4").split(",")]   # kmh_sampler_set_persistent: 0 = one chunk per workgroup
-for variant in VARIANTS:
-    assert lib.kmh_sampler_set_persistent(variant) >= 0
-    print(f"--- bilinear warp kernel: {'sample_fwd_lc_kernel (one chunk per workgroup)' if variant == 0 else f'sample_fwd_p_kernel (persistent, ILP {variant})'}")
-    V = S ** 3
-    t = timeit(lambda: lib.kmh_warp_mse_fwd(p(x), p(grid), p(f), p(out), p(loss), 1, 1, S, S, S, S, S, S, p(ws), st))
-    print(f"warp_mse_fwd   {t*1e3:8.1f} us  {V*24/t/1e6:8.1f} GB/s (24 B/voxel)   loss {float(loss):.6f}")
-    t = timeit(lambda: lib.kmh_grid_sample3d_fwd(p(x), p(grid), p(out), 1, 1, S, S, S, S, S, S, 0, st))
-    print(f"sample_fwd     {t*1e3:8.1f} us  {V*20/t/1e6:8.1f} GB/s (20 B/voxel)   sum {float(out.double().sum()):.4f}")
-    t = timeit(lambda: lib.kmh_grid_sample3d_bwd_grid(p(x), p(grid), p(f), p(dg), 1, 1, S, S, S, S, S, S, st))
-    print(f"sample_bwd_grid{t*1e3:8.1f} us  {V*32/t/1e6:8.1f} GB/s (32 B/voxel)   sum {float(dg.double().abs().sum()):.4f}")
-    for C in (1, 14):
-        xs = torch.rand(1, C, S, S, S, device=dev, generator=g); outs = torch.empty_like(xs)
-        t = timeit(lambda: lib.kmh_grid_sample3d_fwd(p(xs), p(grid), p(outs), 1, C, S, S, S, S, S, S, 0, st), n=10)
-        print(f"sample_fwd C={C:2d} {t*1e3:8.1f} us  {V*(12+8*C)/t/1e6:8.1f} GB/s ({12+8*C} B/voxel)  [KMH_SAMPLER_XCD={os.environ.get('KMH_SAMPLER_XCD','1')}]")
-    t = timeit(lambda: lib.kmh_warp_mse_fwd_grad(p(x), p(grid), p(f), p(out), p(loss), p(dg), 1, 1, S, S, S, S, S, S, p(ws), st))
-    print(f"warp_mse_fwd_grad {t*1e3:8.1f} us  {V*36/t/1e6:8.1f} GB/s (36 B/voxel)")
+V = S ** 3
+t = timeit(lambda: lib.kmh_warp_mse_fwd(p(x), p(grid), p(f), p(out), p(loss), 1, 1, S, S, S, S, S, S, p(ws), st))
+print(f"warp_mse_fwd   {t*1e3:8.1f} us  {V*24/t/1e6:8.1f} GB/s (24 B/voxel)   loss {float(loss):.6f}")
+t = timeit(lambda: lib.kmh_grid_sample3d_fwd(p(x), p(grid), p(out), 1, 1, S, S, S, S, S, S, 0, st))
+print(f"sample_fwd     {t*1e3:8.1f} us  {V*20/t/1e6:8.1f} GB/s (20 B/voxel)   sum {float(out.double().sum()):.4f}")
+t = timeit(lambda: lib.kmh_grid_sample3d_bwd_grid(p(x), p(grid), p(f), p(dg), 1, 1, S, S, S, S, S, S, st))
+print(f"sample_bwd_grid{t*1e3:8.1f} us  {V*32/t/1e6:8.1f} GB/s (32 B/voxel)   sum {float(dg.double().abs().sum()):.4f}")
+for C in (1, 14):
+    xs = torch.rand(1, C, S, S, S, device=dev, generator=g); outs = torch.empty_like(xs)
+    t = timeit(lambda: lib.kmh_grid_sample3d_fwd(p(xs), p(grid), p(outs), 1, C, S, S, S, S, S, S, 0, st), n=10)
+    print(f"sample_fwd C={C:2d} {t*1e3:8.1f} us  {V*(12+8*C)/t/1e6:8.1f} GB/s ({12+8*C} B/voxel)  [KMH_SAMPLER_XCD={os.environ.get('KMH_SAMPLER_XCD','1')}]")
+t = timeit(lambda: lib.kmh_warp_mse_fwd_grad(p(x), p(grid), p(f), p(out), p(loss), p(dg), 1, 1, S, S, S, S, S, S, p(ws), st))
+print(f"warp_mse_fwd_grad {t*1e3:8.1f} us  {V*36/t/1e6:8.1f} GB/s (36 B/voxel)")

@@ -1,12 +1,10 @@
 """A handful of launches of the bilinear warp kernels at 256^3 (for rocprofv3 --pmc passes: few dispatches, no side legs).
-usage: python tools/prof_sampler_min.py [variant: 0 | 2 | 4]   (kmh_sampler_set_persistent)"""
+usage: python tools/prof_sampler_min.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from keymorph_amd import _lib, synthetic
 from keymorph_amd.transformations import AffineTransform
 lib = _lib.load()
-v = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-assert lib.kmh_sampler_set_persistent(v) >= 0
 S, dev = 256, "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.rand(1, 1, S, S, S, device=dev, generator=g)

@@ -1,16 +1,15 @@
 #!/bin/bash
 # Round 6: counters of the bilinear warp kernels (256^3, the bench's affine grid), three launches each of the stand-alone warp
-# and of the fused warp + MSE + d loss / d grid.   tools/profile_sampler.sh r6d [variant]  ->  gpurun_out/r6d_sampler_counters.txt
+# and of the fused warp + MSE + d loss / d grid.   tools/profile_sampler.sh r6d  ->  gpurun_out/r6d_sampler_counters.txt
 # One rocprofv3 pass per SMALL counter group (the TA / TCP blocks take two counters at a time: a group of four aborted rocprofv3
 # with "Request exceeds the capabilities of the hardware to collect" and then hung), every pass under its own timeout;
 # --pmc with --kernel-trace only (no --stats / sys-trace beside --pmc).
 tag=${1:-r6x}
-variant=${2:-0}
 cd /tmp && export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 out=gpurun_out/${tag}_sampler_counters.txt
-echo "== python tools/prof_sampler_min.py $variant  (kmh_sampler_set_persistent($variant); 3 dispatches per kernel)" > $out
+echo "== python tools/prof_sampler_min.py  (3 dispatches per kernel)" > $out
 GROUPS_=(
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
   "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VALU"
@@ -26,7 +25,7 @@ i=0; dirs=""
 for P in "${GROUPS_[@]}"; do
   i=$((i+1))
   rm -rf gpurun_out/sp_$i
-  if timeout 240 rocprofv3 --pmc $P --kernel-trace --output-format csv -d gpurun_out/sp_$i -- python tools/prof_sampler_min.py $variant > gpurun_out/sp_log.txt 2>&1; then
+  if timeout 240 rocprofv3 --pmc $P --kernel-trace --output-format csv -d gpurun_out/sp_$i -- python tools/prof_sampler_min.py > gpurun_out/sp_log.txt 2>&1; then
     dirs="$dirs gpurun_out/sp_$i"
   else
     echo "   (pass failed or timed out: $P :: $(grep -i -m1 'error code\|invalid\|not found' gpurun_out/sp_log.txt | cut -c1-160))" >> $out
