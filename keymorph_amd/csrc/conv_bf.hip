@@ -3159,6 +3159,9 @@ __device__ __forceinline__ void wgrad_mfma_brick(const unsigned char* sXT, const
         acc[j][t] = mfma16<TERMS>(a[j][0], b[t][0], acc[j][t]);
       }
   };
+  // (Round 6, measured and removed: the fragments of row r + 1 read into a second register set before row r's MFMAs -- the
+  // compiler's own order is "rrLM rrrrLM ...", 33 lgkmcnt waits per 48 MFMAs; with the read-ahead 14, all counted (lgkmcnt(10..12))
+  // -- changed no launch: 3.435 / 3.400 ms with / without at 16 -> 32, 2 x 256^3; N = 64 spills.  profiles/r6d_wgrad_readahead_ab.txt)
   if (MODE != 0) {
 #pragma unroll
     for (int row = 0; row < WY * WZ; ++row) one_row(row);
@@ -3508,6 +3511,9 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
   // planes of its window); producers and consumers advance it by the same rule
   const int cz_first = (int)((b_beg - b_base) % tiles_z);
 
+  // (Round 6, measured and removed -- profiles/r6e_wgrad_prio_order_ab.txt: s_setprio 2 on the consumer waves: flat; on the
+  // producer waves: 1-10 % slower (the consumers' stream is the critical path); term-major MFMA order over a row's
+  // accumulators instead of three products of one accumulator back to back: flat.)
   if (wv >= WS_CONS) {
     // ------------------------------------------------------------------------------ producers
     const int pt = tid - 64 * WS_CONS;
