@@ -818,7 +818,12 @@ def main():
                           "whole-path runs at 1e-6..4e-6).  THIS configuration (512 keypoints, lambda = 0, random-init clumped "
                           "keypoints) has cond(A) ~ 1e6: the reference's own fp32 path is 3.8e-4 from the fp64 truth on the "
                           "grid there, and parity is |ours - truth| <= 1.25 |reference - truth| "
-                          "(tests/test_ops_gpu.py::test_tps_k512_lambda0_vs_truth), not a plain 1e-4 statement",
+                          "(tests/test_ops_gpu.py::test_tps_k512_lambda0_vs_truth), not a plain 1e-4 statement.  GRADIENTS (outside "
+                          "north_star's 1e-4 outputs): whole parameter-gradient vector 3.3e-4 from the oracle's fp64 autograd at "
+                          "128^3 / 512 kp where the reference's fp32 is 3.8e-4, BUT the first encoder block's cancelling sums are 3-5 x "
+                          "FURTHER from fp64 than the reference's fp32 (first GroupNorm weight / bias 4.6e-3 / 4.9e-3 against 1.4e-3 / "
+                          "1.0e-3); running that block's data gradient on bf16x6 does not change it (first_block_exact_* keys, "
+                          "DESIGN section 4)",
                 "arithmetic": {"f16x3": "conv: fp32 operands range-scaled by 2^k and split into fp16 hi+lo, 3 MFMA products, "
                                         "fp32 accumulate (5e-7 vs fp64, like fp32 MFMA); the fused 1x1x1 head uses the same scheme",
                                "bf16x6": "fp32 operands split into bf16 hi+mid+lo, 6 MFMA products, fp32 accumulate",

@@ -117,8 +117,12 @@ class Decoder(nn.Module):
 
 class AbstractUNet(nn.Module):
     def __init__(self, in_channels, out_channels, final_sigmoid=True, f_maps=64, layer_order="gcr", num_groups=8,
-                 num_levels=4, is_segmentation=True, conv_padding=1, num_truncated_layers=0, **kwargs):
+                 num_levels=4, is_segmentation=True, conv_padding=1, num_truncated_layers=0, use_checkpoint=False, **kwargs):
         super().__init__()
+        # keymorph/unet3d/model.py:113, :119-144: every encoder / decoder block under torch.utils.checkpoint (non-reentrant):
+        # a block's saved activations are dropped after its forward and recomputed, block by block, during the backward.
+        # The kernels are deterministic, so gradients are bit-identical with and without it (test_use_checkpoint_*).
+        self.use_checkpoint = bool(use_checkpoint)
         if layer_order != "gcr" or conv_padding != 1:
             raise NotImplementedError("keymorph_amd implements the 'gcr', padding=1 U-Net of scripts/run.py")
         if isinstance(f_maps, int):
@@ -177,7 +181,7 @@ class AbstractUNet(nn.Module):
             fuse_pool = (nxt_pools and opm is None and c2._dy_premasked
                          and B.conv_pool_ok(xin.shape[0], xin.shape[1], xin.shape[2], xin.shape[3], c2.conv.in_channels,
                                             c2.conv.out_channels))
-            x = enc.basic_module(xin, opm, out_dy_blocked=blk_out, out_pool=fuse_pool)
+            x = self._block(enc.basic_module, xin, opm, out_dy_blocked=blk_out, out_pool=fuse_pool)
             prev_blk = blk_out
             pooled = x if fuse_pool else None
             if fuse_pool:
@@ -190,8 +194,15 @@ class AbstractUNet(nn.Module):
                 feats.insert(0, (x, False))
         x = feats[0][0]
         for j, (dec, (skip, lazy)) in enumerate(zip(self.decoders, feats[1:])):
-            x = dec(skip, x, lazy, last_pm if j == nd - 1 else None)
+            x = self._block(dec, skip, x, lazy, last_pm if j == nd - 1 else None)
         return x
+
+    def _block(self, fn, *args, **kwargs):
+        """one encoder / decoder block, checkpointed when use_checkpoint (and a backward can follow)"""
+        if self.use_checkpoint and torch.is_grad_enabled():
+            from torch.utils import checkpoint
+            return checkpoint.checkpoint(lambda *a: fn(*a, **kwargs), *args, use_reentrant=False)
+        return fn(*args, **kwargs)
 
     def keypoints_ij(self, x):
         """CenterOfMass3d('ij')(forward(x)) with the 1x1x1 head, ReLU and the center of mass fused (no heat-map).
@@ -234,18 +245,19 @@ class UNet3D(AbstractUNet):
     """keymorph/unet3d/model.py:154-189"""
 
     def __init__(self, in_channels, out_channels, final_sigmoid=True, f_maps=64, layer_order="gcr", num_groups=8,
-                 num_levels=4, is_segmentation=True, conv_padding=1, **kwargs):
+                 num_levels=4, is_segmentation=True, conv_padding=1, use_checkpoint=False, **kwargs):
         super().__init__(in_channels, out_channels, final_sigmoid, f_maps, layer_order, num_groups, num_levels,
-                         is_segmentation, conv_padding, 0)
+                         is_segmentation, conv_padding, 0, use_checkpoint=use_checkpoint)
 
 
 class TruncatedUNet3D(AbstractUNet):
     """keymorph/unet3d/model.py:394-430"""
 
     def __init__(self, in_channels, out_channels, num_truncated_layers, final_sigmoid=True, f_maps=64,
-                 layer_order="gcr", num_groups=8, num_levels=4, is_segmentation=True, conv_padding=1, **kwargs):
+                 layer_order="gcr", num_groups=8, num_levels=4, is_segmentation=True, conv_padding=1,
+                 use_checkpoint=False, **kwargs):
         super().__init__(in_channels, out_channels, final_sigmoid, f_maps, layer_order, num_groups, num_levels,
-                         is_segmentation, conv_padding, num_truncated_layers)
+                         is_segmentation, conv_padding, num_truncated_layers, use_checkpoint=use_checkpoint)
 
 
 # Names the reference's scripts import beside UNet3D / TruncatedUNet3D (scripts/run.py:13, scripts/register.py:11) and that

@@ -144,3 +144,46 @@ def test_two_training_iterations_and_resume(loss_fn, tmp_path):
     ref_opt = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in km2.parameters()], lr=1.0)
     ref_opt.load_state_dict(opt2.state_dict())
     assert ref_opt.param_groups[0]["lr"] == 1e-3
+
+
+@pytest.mark.parametrize("size,levels,trunc", [(64, 4, 1), (40, 3, 0)])
+def test_use_checkpoint_bit_identical_gradients_and_smaller_peak(size, levels, trunc):
+    """use_checkpoint=True (keymorph/unet3d/model.py:113-144: every encoder / decoder block under torch.utils.checkpoint,
+    non-reentrant) recomputes a block's activations during the backward instead of keeping them.  One training step (tps_1,
+    warp + MSE) with and without it from the same weights: loss, keypoints and EVERY parameter gradient bit-identical (the
+    kernels are deterministic, and the gradient hand-offs between blocks -- channel-blocked, pre-split, lazy GroupNorm
+    backward, pool_fork -- cross the checkpoint boundaries unchanged), and the peak of allocated device memory over the step
+    is lower with it."""
+    from keymorph_amd import ops, synthetic
+    from keymorph_amd.model import KeyMorph
+    from keymorph_amd.unet3d.model import TruncatedUNet3D, UNet3D
+    K = 32
+    img_f, img_m = synthetic.make_pair(size, 3, torch.device(DEV))
+
+    def run(ckpt):
+        torch.manual_seed(5)
+        if trunc:
+            net = TruncatedUNet3D(1, K, trunc, final_sigmoid=False, f_maps=16, layer_order="gcr", num_groups=8, num_levels=levels,
+                                  is_segmentation=False, conv_padding=1, use_checkpoint=ckpt)
+        else:
+            net = UNet3D(1, K, final_sigmoid=False, f_maps=16, layer_order="gcr", num_groups=8, num_levels=levels,
+                         is_segmentation=False, conv_padding=1, use_checkpoint=ckpt)
+        assert net.use_checkpoint is ckpt
+        km = KeyMorph(net, K, 3, max_train_keypoints=None, use_checkpoint=ckpt).to(DEV).train()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        r = km(img_f, img_m, transform_type="tps_1", return_aligned_points=False)["tps_1"]
+        loss, _ = ops.warp_mse(img_m, r["grid"], img_f)
+        loss.backward()
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - base
+        return float(loss), r["points_f"].detach().clone(), {k: p.grad.clone() for k, p in km.named_parameters()}, peak
+
+    l0, p0, g0, m0 = run(False)
+    l1, p1, g1, m1 = run(True)
+    assert l0 == l1 and torch.equal(p0, p1)
+    for k in g0:
+        assert torch.isfinite(g0[k]).all() and torch.equal(g0[k], g1[k]), k
+    print(f"use_checkpoint at {size}^3, {levels} levels: peak device memory over the step {m0 / 2**20:.0f} MiB -> {m1 / 2**20:.0f} MiB")
+    assert m1 < 0.85 * m0, (m0, m1)

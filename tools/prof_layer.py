@@ -29,8 +29,14 @@ if blocked:
     gw = B.conv3_wgrad(x, sc, sh, dyb, N, D, D, D, Cin, Cout, False, xscale=asc, dz_blocked=True)
     print("blocked vs NDHWC weight gradient: max |diff| =", float((gw - rw).abs().max()))
 wf, wt = B.pack_weight(w, False), B.pack_weight(w, True)
+xblocked = bool(os.environ.get("KMH_XBLOCKED"))    # FORWARD input in the channel-blocked layout (N, C/8, D, H, W, 8): what would it buy?
+xb = x.view(N, D, D, D, Cin // 8, 8).permute(0, 4, 1, 2, 3, 5).contiguous() if xblocked else None
+if xblocked:
+    r0 = B.conv3_raw(x, sc, sh, wf, None, N, D, D, D, Cin, Cout, False, True, ascale=asc)
+    r1 = B.conv3_raw(xb, sc, sh, wf, None, N, D, D, D, Cin, Cout, False, True, ascale=asc, in_blocked=True)
+    print("blocked vs NDHWC forward: max |diff| =", float((r1 - r0).abs().max()))
 steps = [
-    ("fwd", lambda: B.conv3_raw(x, sc, sh, wf, None, N, D, D, D, Cin, Cout, False, True, ascale=asc)),
+    ("fwd", lambda: B.conv3_raw(xb if xblocked else x, sc, sh, wf, None, N, D, D, D, Cin, Cout, False, True, ascale=asc, in_blocked=xblocked)),
     ("dgrad", lambda: B.conv3_raw(dyb if blocked else dy, None, None, wt, None, N, D, D, D, Cout, Cin, False, False, mask=y if masked else None, in_blocked=blocked)),
     ("wgrad", lambda: B.conv3_wgrad(x, sc, sh, dyb if blocked else dy, N, D, D, D, Cin, Cout, False, dzmask=y if masked else None, xscale=asc, dscale=dsc, dz_blocked=blocked)),
 ]
