@@ -476,9 +476,22 @@ def pool_grad_split_ok(N, D, H, W, Cin, Cout) -> bool:
         bool(lib.kmh_conv3d_wgrad_bf_blocked_ok(N, D, H, W, Cin, Cout, 2))
 
 
+# Layout of a gradient tensor handed from one operator's backward to the next (an attribute on the tensor object, guarded by its
+# version counter): kind 1 = fp32 channel-blocked (N, C/8, D, H, W, 8); kind 2 = PRE-SPLIT records (N, C/8, V + 1, 8 floats =
+# 8 fp16 hi + 8 fp16 lo), what kmh_maxpool3d_bwd_split writes.  Both are "blocked"; a consumer must know which.
+def _tag_blocked(t, kind: int = 1) -> None:
+    t._kmh_blocked = t._version
+    t._kmh_blocked_kind = int(kind)
+
+
 def _is_blocked(t) -> bool:
     tag = getattr(t, "_kmh_blocked", None)
     return tag is not None and tag == t._version
+
+
+def _blocked_kind(t) -> int:
+    """0 = (N,D,H,W,C); 1 = fp32 channel-blocked; 2 = pre-split records"""
+    return int(getattr(t, "_kmh_blocked_kind", 1)) if _is_blocked(t) else 0
 
 
 @_binds_amp
@@ -609,11 +622,15 @@ class _SingleConvGCR(torch.autograd.Function):
             _tag_grad_scale(full, sd_in)       # scattering moves values: the bound of the pooled gradient holds
             dy = full
             if dy_blocked:
-                dy._kmh_blocked = dy._version
+                _tag_blocked(dy, 2 if dy_split else 1)
                 BLOCKED_STATS["handoffs"] += 1
         # ReLU backward (dz = dy * [y > 0]) is fused into the loaders of both gradient kernels -- and is
         # skipped altogether when every consumer of y already returned a gradient masked by (y > 0)
         # (a downstream SingleConv with x_from_relu, possibly through max-pool / upsample+concat).
+        if _blocked_kind(dy) != (2 if dy_split else (1 if (dy_blocked) else 0)):
+            raise RuntimeError("keymorph_amd: gradient layout kind %d where %d was expected (1 = fp32 channel-blocked, 2 = pre-split "
+                               "records); a hook or an in-place op between two operators changed the tensor"
+                               % (_blocked_kind(dy), 2 if dy_split else (1 if dy_blocked else 0)))
         ymask = None if dy_premasked else y
         first = Cin == 1 and not ctx.needs_input_grad[0] and (Cout <= 16 or CONV_MODE != "f32")
         dscale = (grad_scale(dy) if (_needs_range_scales() and not (first and Cout <= 16)) else None)
@@ -673,7 +690,7 @@ class _SingleConvGCR(torch.autograd.Function):
                                            int(dx_blocked), _stream()), "kmh_gn_bwd_apply")
                 _tag_grad_scale(dx, sc2)
                 if dx_blocked:
-                    dx._kmh_blocked = dx._version
+                    _tag_blocked(dx, 1)
                     BLOCKED_STATS["handoffs"] += 1
         return dx, dgamma, dbeta, dw, None, None, None, None, None, None, None, None, None
 
@@ -954,7 +971,7 @@ def _maxpool_bwd(ctx, dy, add, out_blocked=False):
     check(lib.kmh_maxpool3d_bwd(None, _p(arg), _p(dy_c), _p(add), acs, _p(dx), N, D, H, W, C, int(out_blocked),
                                 _stream()), "kmh_maxpool3d_bwd")
     if out_blocked:
-        dx._kmh_blocked = dx._version
+        _tag_blocked(dx, 1)
         BLOCKED_STATS["handoffs"] += 1
     # scattering moves values: the bound of dy holds for dx (plus the skip gradient's bound when that is added)
     sd = _peek_grad_scale(dy)

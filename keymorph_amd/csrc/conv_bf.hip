@@ -2873,7 +2873,12 @@ KMH_API int kmh_conv3d_fwd_bf_variant(int N, int D, int H, int W, int Cin, int C
 KMH_API int kmh_conv3d_fwd_bf_split_ok(int N, int D, int H, int W, int Cin, int Cout, int terms) {
   if (!use_zpair(Cout) || Cin > S_COEF) return 0;
   if (((long long)D * H * W + 1) * KC >= (1ll << 31)) return 0;
-  return fwd_g_ok(false, false, N, D, H, W, Cin, Cout, terms) ? 1 : 0;
+  // The shape's own preconditions only -- NOT the tunable dispatch threshold (kmh_conv3d_fwd_bf_set_dispatch / KEYMORPH_FWD_G):
+  // in_blocked == 2 always launches conv3_fwd_s_kernel<1, true, true>, whatever the mode, and a producer that asked this
+  // question at forward time must get the same answer at backward time.
+  if (N <= 0 || terms != 2 || (Cin & 7) || (Cout & 3)) return 0;
+  if ((long long)D * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31)) return 0;          // 32-bit element offsets
+  return 1;
 }
 
 /* Convolution + ReLU + MaxPool3d(2) in one launch, for an encoder block whose output feeds ONLY the next level's pooling

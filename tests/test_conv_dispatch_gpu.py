@@ -649,9 +649,12 @@ def test_presplit_operand_refused_where_it_is_not_served(dispatch):
     assert lib.kmh_conv3d_fwd_bf_split_ok(1, 8, 16, 64, 32, 32, 2) == 0           # not the z-paired tile
     assert lib.kmh_conv3d_fwd_bf_split_ok(1, 8, 16, 64, 32, 16, 3) == 0           # bf16x6
     assert lib.kmh_conv3d_fwd_bf_split_ok(1, 8, 16, 64, 12, 16, 2) == 0           # whole chunks only
-    dispatch(1)
-    assert lib.kmh_conv3d_fwd_bf_split_ok(1, 8, 16, 64, 32, 16, 2) == 0           # below 512 bricks in the default mode
-    assert lib.kmh_conv3d_fwd_bf_split_ok(4, 256, 256, 256, 32, 16, 2) == 1
+    # (round 6, ADVICE r5: the answer is the SHAPE's, not the dispatch mode's -- in_blocked = 2 always launches the one-wave
+    # z-paired kernel, and a producer that asked at forward time must get the same answer at backward time)
+    for mode in (0, 1, 2):
+        dispatch(mode)
+        assert lib.kmh_conv3d_fwd_bf_split_ok(1, 8, 16, 64, 32, 16, 2) == 1
+        assert lib.kmh_conv3d_fwd_bf_split_ok(4, 256, 256, 256, 32, 16, 2) == 1
 
 
 @pytest.mark.parametrize("cfg", [(2, (12, 16, 64), 16, 32), (2, (44, 60, 100), 16, 32), (1, (30, 62, 122), 8, 24)])
