@@ -3024,7 +3024,17 @@ constexpr int WV = WX * WY * WZ;           // 128
 // multiplied, up to 4 being filled (the first brick of a z column fills all 4 and starts 4 planes further on, so it never
 // touches what the previous column's last brick is still being read from).
 constexpr int RZ = 8;                                  // ring planes
-constexpr int XPLANE_R = RZ * WHY * XPITCH * 2 + 16;   // 2320 bytes per channel plane of the ring image (= 145 x 16 B: odd, as 1168 = 73 x 16)
+// Plane pitch of the ring image: 2312 bytes = 578 words, i.e. 2 mod 32.  The consumers' A fragments are five dwords per lane that
+// the compiler reads with 4-byte instructions (ds_read2_b32: it scalarises a 16-byte load whose dwords feed the funnel shifts one by
+// one), whose 32-lane groups are 16 channels x 2 taps: with the pitch at 4 mod 32 words (2320 B = 145 x 16 B, chosen in round 2 for
+// 16-byte reads that the compiler never emitted) 32 lanes hit 8 banks -- 57 % of the LDS-active cycles were bank conflicts and the LDS
+// was 86 % busy (profiles/r6i_sq_counters_wgrad_ring.txt).  At 2 mod 32 the channels take 16 distinct banks and the producers'
+// 4-byte stores (channel quads 8 banks apart) stay conflict-free: -6 ... -11 % on every launch; 6, 10, 18 mod 32 the same, an ODD
+// pitch twice as slow (profiles/r6k_wgrad_ring_pitch_ab.txt).  KMH_WG_RPAD (A/B builds): bytes added to the 2304 of the rows.
+#ifndef KMH_WG_RPAD
+#define KMH_WG_RPAD 8
+#endif
+constexpr int XPLANE_R = RZ * WHY * XPITCH * 2 + KMH_WG_RPAD;
 constexpr int ZSLOT = WHY * XPITCH * 2;                // 288 bytes per ring plane inside a channel plane
 constexpr int WGB_TPB = 512;
 constexpr int MTWB = 2;                    // M tiles per wave (14 tiles over 8 waves)
@@ -3113,8 +3123,15 @@ __device__ __forceinline__ void wgrad_mfma_brick(const unsigned char* sXT, const
       for (int q = 0; q < TERMS; ++q) {
         if (MODE == 1 ? j == 0 : (MODE == 2 || j == 0 || !w.share_a)) {
           const unsigned char* p = sXT + q * xt_bytes + w.abase[j] + (RING ? zo[j][zz] : 0) + arow;
-          wq[q] = *reinterpret_cast<const uint4*>(p);
-          w4q[q] = *reinterpret_cast<const unsigned*>(p + 16);
+          if constexpr (RING) {
+            // five dwords, read AS dwords (the ring's plane pitch is a multiple of 8, not of 16 bytes: see XPLANE_R)
+            const unsigned* p32 = reinterpret_cast<const unsigned*>(p);
+            wq[q] = make_uint4(p32[0], p32[1], p32[2], p32[3]);
+            w4q[q] = p32[4];
+          } else {
+            wq[q] = *reinterpret_cast<const uint4*>(p);
+            w4q[q] = *reinterpret_cast<const unsigned*>(p + 16);
+          }
         }
         const uint4 v = wq[q];
         const unsigned v4 = w4q[q];
