@@ -3034,8 +3034,16 @@ constexpr int RZ = 8;                                  // ring planes
 #ifndef KMH_WG_RPAD
 #define KMH_WG_RPAD 8
 #endif
-constexpr int XPLANE_R = RZ * WHY * XPITCH * 2 + KMH_WG_RPAD;
-constexpr int ZSLOT = WHY * XPITCH * 2;                // 288 bytes per ring plane inside a channel plane
+#ifndef KMH_WG_RROW
+#define KMH_WG_RROW 24          // elements (2 bytes) per halo row of the ring image (18 used; a lane reads 5 dwords from byte 0 or 16)
+#endif
+#ifndef KMH_WG_RZPAD
+#define KMH_WG_RZPAD 0          // bytes added to a ring plane
+#endif
+constexpr int XPITCH_R = KMH_WG_RROW;
+constexpr int ZSLOT = WHY * XPITCH_R * 2 + KMH_WG_RZPAD;   // bytes per ring plane inside a channel plane
+constexpr int XPLANE_R = RZ * ZSLOT + KMH_WG_RPAD;
+static_assert(XPITCH_R * 2 >= 36 && (XPLANE_R & 3) == 0 && (ZSLOT & 3) == 0, "a row holds 18 elements; dword-aligned planes");
 constexpr int WGB_TPB = 512;
 constexpr int MTWB = 2;                    // M tiles per wave (14 tiles over 8 waves)
 
@@ -3075,7 +3083,7 @@ __device__ __forceinline__ WgradTiles wgrad_deal_tiles(int CP, int MT, int TG, i
     w.abase[j] = valid ? (c * XPLANE + (kz * WHY + ky) * (XPITCH * 2) + 16 * lh) : (CP * XPLANE + 16 * lh);
     w.akz[j] = 0;
     if (ring) {      // the z offset is added per brick: ((ring base + row plane + kz) mod RZ) planes (the zero plane: any)
-      w.abase[j] = valid ? (c * XPLANE_R + ky * (XPITCH * 2) + 16 * lh) : (CP * XPLANE_R + 16 * lh);
+      w.abase[j] = valid ? (c * XPLANE_R + ky * (XPITCH_R * 2) + 16 * lh) : (CP * XPLANE_R + 16 * lh);
       w.akz[j] = valid ? kz : 0;
     }
     w.akx[j] = __builtin_amdgcn_readfirstlane(m < MT ? kx : 0);
@@ -3106,7 +3114,7 @@ __device__ __forceinline__ void wgrad_mfma_brick(const unsigned char* sXT, const
     for (int z = 0; z < WZ; ++z) zo[j][z] = RING ? ((ring_base + z + w.akz[j]) & (RZ - 1)) * ZSLOT : 0;
   auto one_row = [&](int row) {
     const int zz = row / WY, yy = row - zz * WY;
-    const int arow = RING ? yy * (XPITCH * 2) : (zz * WHY + yy) * (XPITCH * 2);
+    const int arow = RING ? yy * (XPITCH_R * 2) : (zz * WHY + yy) * (XPITCH * 2);
     const int brow = row * WX * 2;
     bf16x8 b[NT][TERMS];
 #pragma unroll
@@ -3558,7 +3566,7 @@ __global__ __launch_bounds__(64 * (WS_CONS + PW), (PW == 8 ? 4 : 3)) void conv3_
       const int cb = 4 * cpart;
       const bool on = (e < x_items) && (ci0 + cb < Cin);
       xi_pk[i] = on ? (lz | (ly << 4) | ((2 * pr) << 8) | (cb << 16) | (1 << 30)) : 0;   // off: loads a valid dummy
-      xi_lds[i] = cb * XPLANE_R + (ly * XPITCH + 2 * pr) * 2;                               // + the ring plane's ZSLOT, per brick
+      xi_lds[i] = cb * XPLANE_R + (ly * XPITCH_R + 2 * pr) * 2;                               // + the ring plane's ZSLOT, per brick
     }
     int di_pk[DI], di_lds[DI], di_q4[DI];
 #pragma unroll
