@@ -2233,6 +2233,9 @@ __global__ __launch_bounds__(256) void up2_wgrad_reduce_kernel(const float* __re
 #ifndef WF_DMA                 // 1 = the dz window by LDS-DMA (0: through registers, the A/B arm)
 #define WF_DMA 1
 #endif
+#ifndef KMH_WF_MAP
+#define KMH_WF_MAP 1
+#endif
 #ifndef WF_EARLY_W
 #define WF_EARLY_W 1
 #endif
@@ -2378,7 +2381,15 @@ __global__ __launch_bounds__(MODE ? 512 : 256, MODE ? 1 : 2) void up2_wgrad_fold
     if (bt >= 192) return;
     const float4* sW = reinterpret_cast<const float4*>(sW0 + iw_t * W_BYTES);
     unsigned char* sB = sB0 + iw_t * B_BYTES;
+#if KMH_WF_MAP
+    // a WAVE = one kz: (q, low voxel m) vary over its lanes.  With kz across the lanes (round 5) three lanes of every quad of
+    // lanes wrote the same bank of the B image (72 columns x 80 bytes = 0 mod 128 bytes between the kz groups) and read window
+    // planes 32 banks apart: 58 % of the kernel's LDS-active cycles were bank conflicts at 59 % LDS busy
+    // (profiles/r6n_lds_by_kernel.txt).  Same sums per (m, kz, q), same order: bit-identical.
+    const int q = bt & 1, kz = bt >> 6, m = (bt >> 1) & 31;
+#else
     const int q = bt & 1, kz = (bt >> 1) % 3, m = bt / 6;
+#endif
     const int lmx = m & 3, lmy = (m >> 2) & 3, lmz = m >> 4;
     float4 Y[3][3];
 #pragma unroll
