@@ -447,3 +447,46 @@ def test_bench_transport_check_allreduce_expectation_and_profile_manifest(tmp_pa
     mb, src = bench.pmc_traffic("conv3_fwd_")
     tag = open(os.path.join(root, "profiles", "LATEST")).read().split()[0]
     assert src == f"{tag}_pmc_hbm_traffic.json" and mb and mb > 1e8, (mb, src)
+
+
+def test_amp_scope_is_per_thread_and_travels_with_the_autograd_node():
+    """use_amp is per call (round 6): `amp_scope` is a per-thread setting that ends with the `with` block, `_t` turns it
+    into the `terms = 1` the C ABI takes, and a Function decorated with `_binds_amp` runs its BACKWARD under the setting of its
+    own forward -- whatever another model set in between, and although autograd runs the backward on another thread."""
+    import threading
+    from keymorph_amd import backbone_ops as B
+    assert B.amp_enabled() is B._AMP_DEFAULT
+    with B.amp_scope(True):
+        assert B.amp_enabled() and B._t(2) == 1 and B._t(3) == 3
+        seen = []
+        th = threading.Thread(target=lambda: seen.append(B.amp_enabled()))      # another thread: its own default
+        th.start(); th.join()
+        assert seen == [B._AMP_DEFAULT]
+        with B.amp_scope(False):
+            assert not B.amp_enabled() and B._t(2) == 2
+        assert B.amp_enabled()
+    assert B.amp_enabled() is B._AMP_DEFAULT
+
+    log = []
+
+    @B._binds_amp
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            log.append(("fwd", B.amp_enabled()))
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            log.append(("bwd", B.amp_enabled(), threading.current_thread() is threading.main_thread()))
+            return g * 2
+
+    x = torch.ones(3, requires_grad=True)
+    with B.amp_scope(True):
+        y = F.apply(x)
+    with B.amp_scope(False):                       # "another model" between the forward and the backward
+        F.apply(torch.ones(1, requires_grad=True))
+    y.sum().backward()
+    assert log[0] == ("fwd", True) and log[1] == ("fwd", False)
+    assert log[2][0] == "bwd" and log[2][1] is True            # the forward's setting, not the last one seen
+    assert torch.equal(x.grad, torch.full((3,), 2.0)) and B.amp_enabled() is B._AMP_DEFAULT
